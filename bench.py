@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- dense gen.phi throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pass of the hot path: all level steps of gen.phi (Psi = 1/2 I ... the
+N x N proband matrix, delivered in proband order) for the synthetic pedigree of the named
+workload, with the pedigree's flat index arrays already resident in HBM and the result left
+resident in HBM.  Default workload = the configuration the metric is quoted on
+(BASELINE.json configs[3]: 1e6 individuals / 1e5 probands / 30 generations; fits one GPU).
+
+N > 1: one process per GPU; the upper levels are replicated (a per-level exchange over xGMI
+would cost more than recomputing them), the final level is row-sharded, no
+data-path collective.  Total work is fixed as N grows => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (n_ind, n_pro, n_gen) of synth.random_mating, or a special tag
+    "cfg4": (1_000_000, 100_000, 30),
+    "cfg3": (100_000, 10_000, 20),
+    "cfg2": "genea140",
+    "cfg5": "deep_inbred",
+}
+
+
+def load_workload(name):
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    w = WORKLOADS[name]
+    if w == "genea140":
+        ped = gen.genealogy(gen.genea140)
+        return ped, gen.pro(ped), "genea140 bundled pedigree (41523 individuals, 140 probands)"
+    if w == "deep_inbred":
+        ind, fa, mo, sex, pro = synth.deep_inbred(200, 50, 3)
+        desc = "deep consanguineous synthetic pedigree (1e4 individuals, 200 generations x 50, 3 sires/generation)"
+    else:
+        ind, fa, mo, sex, pro = synth.random_mating(*w)
+        desc = (f"synthetic random-mating pedigree, {w[0]} individuals / {w[1]} probands / {w[2]} generations, "
+                f"SplitMix64 seed {synth.SEED}")
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    return ped, pro, desc
+
+
+def cpu_baseline(ped, pro, sizes, budget_s=20.0):
+    """The oracle (a C/OpenMP port of the reference algorithm, kind "port") timed on this
+    host's cores on a bounded sample: the first level steps of the same pedigree, until about
+    budget_s seconds of work; extrapolated to the whole sweep by (i <= j) kernel evaluations."""
+    from oracle import oracle as O
+    oped = O.Pedigree(ped.ind, ped.father, ped.mother, sort=False)
+    evals_total = sum(n * (n + 1) // 2 for n in sizes[1:])
+    n_pro = sizes[-1]
+    # choose how many level steps to run: probe one step, then size the sample
+    t0 = time.perf_counter()
+    _, done1 = oped.phi(pro, stop_after_levels=1) if len(sizes) > 2 else (None, 0)
+    t1 = time.perf_counter() - t0
+    if len(sizes) <= 2 or done1 == 0:
+        t0 = time.perf_counter()
+        oped.phi(pro)
+        t = time.perf_counter() - t0
+        return {"value": n_pro * n_pro / t, "unit": "proband-pairs/s", "cores": O.num_threads(), "kind": "port",
+                "sample": "the whole workload, one run of the C/OpenMP oracle"}
+    rate1 = done1 / max(t1, 1e-9)
+    k, acc = 1, 0
+    for n in sizes[1:-1]:
+        acc += n * (n + 1) // 2
+        if acc / rate1 > budget_s:
+            break
+        k += 1
+    k = max(1, min(k, len(sizes) - 2))
+    t0 = time.perf_counter()
+    _, done = oped.phi(pro, stop_after_levels=k)
+    t = time.perf_counter() - t0
+    rate = done / t
+    t_est = evals_total / rate
+    return {"value": n_pro * n_pro / t_est, "unit": "proband-pairs/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"first {k} of {len(sizes) - 1} level steps of the same pedigree ({done:.3g} of {evals_total:.3g} "
+                      f"pair-kernel evaluations, {t:.1f} s, C/OpenMP oracle = port of src/compute.jl:105-158,233-304), "
+                      f"extrapolated by evaluation count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the gen.phi product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import genlib_jl_amd as gen
+    ped, pro, desc = load_workload(args.workload)
+    pl = gen.plan(ped, pro)
+    sizes, both = pl.levels()
+    n = pl.n_probands
+    # final-level row shard of this rank (proband tiles across the GPUs; no collective)
+    r0, r1 = (n * rank) // world, (n * (rank + 1)) // world
+    rows = (r0, r1) if world > 1 else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, level_ms, perm_ms = 0.0, None, 0.0
+    for _ in range(args.steps):
+        st = pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows, timing=True)
+        kernel_ms += st.total_ms
+        perm_ms += st.perm_ms
+        lm = np.array(st.level_ms[:st.n_steps], dtype=np.float64)
+        level_ms = lm if level_ms is None else level_ms + lm
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = wall * 1e3 / K
+        value = n * n / (wall / K)
+        # roofline of the dominant kernel (the level kernel; every level step launches it once).
+        # algorithmic bytes per launch = 4 (n_k^2 + n_{k+1}^2); for a sharded
+        # final level the launch writes only its rows.
+        byt = [4.0 * (a * a + b * b) for a, b in zip(sizes[:-1], sizes[1:])]
+        if world > 1 and byt:
+            byt[-1] = 4.0 * (sizes[-2] ** 2 + (r1 - r0) * sizes[-1])
+        lvl = (level_ms / K) if level_ms is not None and len(byt) else np.zeros(0)
+        lvl_kernel = lvl.copy()
+        if len(lvl_kernel):
+            lvl_kernel[-1] -= perm_ms / K                 # the proband-order pass is a different kernel
+        tot_b, tot_ms = float(sum(byt)), float(lvl_kernel.sum())
+        achieved = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline",
+            "value": value, "unit": "proband-pairs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 accumulate over f32 storage", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(sizes),
+                       "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes / 1e9,
+                       "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
+                       "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,
+                       "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None},
+            "roofline": {"bound": "hbm", "kernel": "level_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
+                         "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),
+                         "whole_step_frac": (pl.algorithmic_bytes / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if kernel_ms > 0 else None},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
+        print(json.dumps(out), flush=True)
+    pl.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

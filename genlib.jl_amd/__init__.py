@@ -1,0 +1,188 @@
+"""genlib.jl_amd -- MI355X-native drop-in for GenLib.jl's dense kinship matrix `gen.phi`.
+
+Host-side mirror of the reference interface for this ONE path (the reference's host
+language, Julia, is not available in the build image; the Julia shim that a GenLib.jl
+maintainer would add is in julia/GenLibAMD.jl and INTEGRATION.md).  Same names, argument
+meaning, printed lines and error behaviour as the reference:
+
+    import genlib_jl_amd as gen            # loader shim at the repo root
+    ped = gen.genealogy(gen.geneaJi)       # src/create.jl:161-189 (+ depth sort :196-254)
+    gen.pro(ped); gen.founder(ped)         # src/identify.jl:35-39, :15-19
+    phi = gen.phi(ped, verbose=True)       # src/compute.jl:233-304 -> float32 (N, N)
+
+All kinship arithmetic runs in hand-written HIP kernels behind the C-ABI in
+include/genphi.h (csrc/genphi_hip.hip); there is no CPU fallback.
+"""
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import PhiPlan, GenphiDeviceError, GenphiLibraryMissing  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+# bundled example pedigrees (the reference exports the same names, src/GenLib.jl:27,43)
+geneaJi = os.path.join(_ROOT, "tests", "golden", "geneaJi.csv")
+genea140 = os.path.join(_ROOT, "tests", "golden", "genea140.csv")
+
+
+class Pedigree:
+    """Rank-ordered pedigree: what `gen.genealogy` returns (src/create.jl:60-74, :234-254).
+
+    Arrays are in rank order (parents before children); `rank` of ind[k] is k + 1.
+    Parent id 0 = unknown.
+    """
+
+    def __init__(self, ind, father, mother, sex):
+        self.ind = np.ascontiguousarray(ind, dtype=np.int64)
+        self.father = np.ascontiguousarray(father, dtype=np.int64)
+        self.mother = np.ascontiguousarray(mother, dtype=np.int64)
+        self.sex = np.ascontiguousarray(sex, dtype=np.int64)
+        self._index = None
+
+    def __len__(self):
+        return len(self.ind)
+
+    def _idx(self):
+        if self._index is None:
+            order = np.argsort(self.ind, kind="stable")
+            self._index = (self.ind[order], order)
+        return self._index
+
+    def positions(self, ids):
+        """Rank positions of the given IDs; KeyError on an unknown ID (OrderedDict lookup)."""
+        ids = np.asarray(ids, dtype=np.int64)
+        keys, order = self._idx()
+        k = np.searchsorted(keys, ids)
+        k = np.clip(k, 0, len(keys) - 1) if len(keys) else k
+        bad = (len(keys) == 0) | (keys[k] != ids) if len(ids) else np.zeros(0, bool)
+        if np.any(bad):
+            raise KeyError(int(ids[np.argmax(bad)]))
+        return order[k]
+
+    def __contains__(self, ID):
+        keys, _ = self._idx()
+        k = np.searchsorted(keys, ID)
+        return k < len(keys) and keys[k] == ID
+
+    def __repr__(self):
+        return f"Pedigree({len(self)} individuals)"
+
+
+def _read_table(source):
+    if isinstance(source, (str, os.PathLike)):
+        # src/create.jl:161-189: header skipped, whitespace-separated ind father mother sex
+        rows = np.loadtxt(source, dtype=np.int64, skiprows=1, ndmin=2)
+        return rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+    # DataFrame-like / mapping with the reference's column names (src/create.jl:131-146)
+    get = (lambda k: np.asarray(source[k])) if not hasattr(source, "to_dict") else (lambda k: source[k].to_numpy())
+    return tuple(np.asarray(get(k), dtype=np.int64) for k in ("ind", "father", "mother", "sex"))
+
+
+def genealogy(source, sort=True):
+    """gen.genealogy(filename | dataframe; sort=true)  (src/create.jl:131-189).
+
+    With sort=True individuals are ordered by maximum ancestral depth (founders = 1) with a
+    STABLE sort over input order (src/create.jl:196-227); the position in that order is the
+    `rank` the kinship recursion branches on.  With sort=False the input order is kept and a
+    parent listed after its child raises KeyError, as `_finalize_pedigree` does.
+    """
+    ind, father, mother, sex = (np.ascontiguousarray(a, dtype=np.int64) for a in _read_table(source))
+    n = len(ind)
+    if len(np.unique(ind)) != n:
+        # the reference's Dict keeps the last duplicate; we refuse instead of guessing
+        raise ValueError("duplicate individual IDs")
+    if sort and n:
+        order_ids = np.argsort(ind, kind="stable")
+        keys = ind[order_ids]
+
+        def lookup(p):
+            k = np.clip(np.searchsorted(keys, p), 0, n - 1)
+            ok = keys[k] == p
+            if np.any((p != 0) & ~ok):
+                raise KeyError(int(p[np.argmax((p != 0) & ~ok)]))
+            return np.where(p != 0, order_ids[k], -1)
+
+        pf, pm = lookup(father), lookup(mother)
+        depth = np.ones(n, dtype=np.int64)
+        # depth(x) = 1 + max(depth(father), depth(mother)); fixed point in max-depth sweeps
+        for _ in range(n + 1):
+            df = np.where(pf >= 0, depth[np.maximum(pf, 0)], 0)
+            dm = np.where(pm >= 0, depth[np.maximum(pm, 0)], 0)
+            new = np.maximum(df, dm) + 1
+            if np.array_equal(new, depth):
+                break
+            depth = new
+            if depth.max() > n:
+                raise ValueError("pedigree contains a cycle")
+        else:
+            raise ValueError("pedigree contains a cycle")
+        order = np.argsort(depth, kind="stable")
+        ind, father, mother, sex = ind[order], father[order], mother[order], sex[order]
+    ped = Pedigree(ind, father, mother, sex)
+    # parents must precede children (src/create.jl:240-241: KeyError otherwise)
+    pos = np.arange(n)
+    for parent in (ped.father, ped.mother):
+        has = parent != 0
+        if np.any(has):
+            ppos = ped.positions(parent[has])
+            if np.any(ppos >= pos[has]):
+                raise KeyError(int(parent[has][np.argmax(ppos >= pos[has])]))
+    return ped
+
+
+def pro(pedigree):
+    """gen.pro: IDs of individuals without children, ascending (src/identify.jl:35-39)."""
+    parents = np.union1d(pedigree.father, pedigree.mother)
+    return np.sort(pedigree.ind[~np.isin(pedigree.ind, parents)])
+
+
+def founder(pedigree):
+    """gen.founder: IDs with neither parent known, ascending (src/identify.jl:15-19)."""
+    return np.sort(pedigree.ind[(pedigree.father == 0) & (pedigree.mother == 0)])
+
+
+def plan(pedigree, probandIDs=None):
+    """Levelise `pedigree` for `probandIDs` (host only; no GPU needed)."""
+    probandIDs = pro(pedigree) if probandIDs is None else np.asarray(probandIDs, dtype=np.int64)
+    return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs)
+
+
+def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, kernel=0):
+    """gen.phi(pedigree, probandIDs = pro(pedigree); verbose=false, compute=true).
+
+    Returns the square float32 matrix of pairwise kinship coefficients between probands
+    (rows/columns in `probandIDs` order, duplicates collapsed), or None when compute=False.
+    Prints the reference's cut-vertex lines (src/compute.jl:257-260, :281-284).
+    Raises KeyError for an unknown proband ID.  Runs on the GPU (no CPU fallback).
+    """
+    pl = plan(pedigree, probandIDs)
+    try:
+        sizes, both = pl.levels()
+        nsteps = max(len(sizes) - 1, 0)
+        if verbose or not compute:
+            for i in range(nsteps):
+                print(f"Step {i + 1} of {nsteps}: {sizes[i]} founders, {sizes[i + 1]} probands, {both[i]} both.")
+        if not compute:
+            return None
+        if verbose:
+            # the reference prints these inside the level loop; the GPU sweep is one blocking
+            # call, so they are printed just before it
+            for k in range(nsteps):
+                print(f"Running step {k + 1} of {nsteps} ({sizes[k]} founders, {sizes[k + 1]} probands, {both[k]} both).")
+        return pl.compute(device=device, kernel=kernel)
+    finally:
+        pl.close()
+
+
+def phiMean(phi_matrix):
+    """gen.phiMean(::Matrix{Float32}) (src/compute.jl:454-459): mean off-diagonal kinship,
+    accumulated in float32 like the reference (host-side; an on-device reduction is a
+    SURVEY.md 8(f) "next" row)."""
+    m = np.asarray(phi_matrix, dtype=np.float32)
+    total = np.float32(m.sum(dtype=np.float32))
+    diagonal = np.float32(np.diagonal(m).sum(dtype=np.float32))
+    total = np.float32(total - diagonal)
+    return np.float32(total / np.float32(m.size - m.shape[0]))

@@ -1,0 +1,190 @@
+"""ctypes binding of include/genphi.h (the same symbols the Julia shim `ccall`s).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is usable the
+calls raise -- the product path never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgenphi.so")
+
+GENPHI_OK = 0
+GENPHI_ERR_UNKNOWN_ID = 1
+GENPHI_ERR_ORDER = 2
+GENPHI_ERR_DUPLICATE_ID = 3
+GENPHI_ERR_ALLOC = 4
+GENPHI_ERR_DEVICE = 5
+GENPHI_ERR_ARG = 6
+
+GENPHI_MAX_STAT_LEVELS = 1024
+
+_I64P = C.POINTER(C.c_int64)
+_F32P = C.POINTER(C.c_float)
+
+
+class GenphiOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("kernel", C.c_int32), ("row_begin", C.c_int64),
+                ("row_end", C.c_int64), ("timing", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GenphiStats(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("timed", C.c_int32), ("total_ms", C.c_double),
+                ("final_ms", C.c_double), ("perm_ms", C.c_double), ("algorithmic_bytes", C.c_double), ("max_cut", C.c_int64),
+                ("level_ms", C.c_float * GENPHI_MAX_STAT_LEVELS)]
+
+
+# every symbol include/genphi.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands",
+    "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
+    "genphi_result_to_host", "genphi_compute_f32", "genphi_plan_destroy", "genphi_last_error",
+    "genphi_version",
+]
+
+_lib = None
+
+
+class GenphiLibraryMissing(RuntimeError):
+    pass
+
+
+class GenphiDeviceError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GenphiLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for gen.phi.")
+        L = C.CDLL(LIB_PATH)
+        L.genphi_plan_create.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.POINTER(C.c_void_p)]
+        L.genphi_plan_create.restype = C.c_int
+        L.genphi_plan_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_I64P), C.POINTER(_I64P)]
+        L.genphi_plan_levels.restype = C.c_int
+        L.genphi_plan_n_probands.argtypes = [C.c_void_p]
+        L.genphi_plan_n_probands.restype = C.c_int64
+        L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
+        L.genphi_plan_algorithmic_bytes.restype = C.c_double
+        L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
+        L.genphi_compute_device.restype = C.c_int
+        L.genphi_result_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _I64P, _I64P, _I64P]
+        L.genphi_result_device.restype = C.c_int
+        L.genphi_result_to_host.argtypes = [C.c_void_p, _F32P]
+        L.genphi_result_to_host.restype = C.c_int
+        L.genphi_compute_f32.argtypes = [C.c_void_p, _F32P, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
+        L.genphi_compute_f32.restype = C.c_int
+        L.genphi_plan_destroy.argtypes = [C.c_void_p]
+        L.genphi_plan_destroy.restype = None
+        L.genphi_last_error.restype = C.c_char_p
+        L.genphi_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().genphi_last_error().decode("utf-8", "replace")
+
+
+def _raise(rc):
+    msg = last_error()
+    if rc in (GENPHI_ERR_UNKNOWN_ID, GENPHI_ERR_ORDER):
+        raise KeyError(msg)                      # the reference raises KeyError for both
+    if rc == GENPHI_ERR_DUPLICATE_ID or rc == GENPHI_ERR_ARG:
+        raise ValueError(msg)
+    if rc == GENPHI_ERR_ALLOC:
+        raise MemoryError(msg)
+    raise GenphiDeviceError(msg)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class PhiPlan:
+    """Owns a genphi_plan: levelisation + flat index arrays (host), level matrices (device)."""
+
+    def __init__(self, ind, father, mother, pro_ids):
+        L = lib()
+        ind, father, mother, pro_ids = _i64(ind), _i64(father), _i64(mother), _i64(pro_ids)
+        h = C.c_void_p()
+        rc = L.genphi_plan_create(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P),
+                                  mother.ctypes.data_as(_I64P), len(pro_ids), pro_ids.ctypes.data_as(_I64P),
+                                  C.byref(h))
+        if rc:
+            _raise(rc)
+        self._h = h
+        self.stats = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().genphi_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_probands(self):
+        return int(lib().genphi_plan_n_probands(self._h))
+
+    @property
+    def algorithmic_bytes(self):
+        return float(lib().genphi_plan_algorithmic_bytes(self._h))
+
+    def levels(self):
+        """(cut_sizes, both_counts): top founders first."""
+        nl = C.c_int32()
+        cs, bc = _I64P(), _I64P()
+        rc = lib().genphi_plan_levels(self._h, C.byref(nl), C.byref(cs), C.byref(bc))
+        if rc:
+            _raise(rc)
+        n = nl.value
+        return [int(cs[k]) for k in range(n)], [int(bc[k]) for k in range(max(n - 1, 0))]
+
+    def _opts(self, device, kernel, rows, timing):
+        o = GenphiOpts()
+        o.device = -1 if device is None else int(device)
+        o.kernel = int(kernel)
+        o.row_begin, o.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
+        o.timing = 1 if timing else 0
+        return o
+
+    def compute_device(self, device=None, kernel=0, rows=None, timing=False):
+        """Run all level steps on the GPU; the result stays resident in HBM."""
+        o = self._opts(device, kernel, rows, timing)
+        st = GenphiStats()
+        rc = lib().genphi_compute_device(self._h, C.byref(o), C.byref(st))
+        if rc:
+            _raise(rc)
+        self.stats = st
+        return st
+
+    def result_device(self):
+        """(device pointer, row pitch in floats, first row, number of rows) of the resident result."""
+        ptr, ld, r0, nr = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+        rc = lib().genphi_result_device(self._h, C.byref(ptr), C.byref(ld), C.byref(r0), C.byref(nr))
+        if rc:
+            _raise(rc)
+        return ptr.value, ld.value, r0.value, nr.value
+
+    def result_to_host(self):
+        _, _, _, nr = self.result_device()
+        n = self.n_probands
+        out = np.empty((nr, n), dtype=np.float32)
+        rc = lib().genphi_result_to_host(self._h, out.ctypes.data_as(_F32P))
+        if rc:
+            _raise(rc)
+        return out
+
+    def compute(self, device=None, kernel=0, rows=None, timing=False):
+        self.compute_device(device=device, kernel=kernel, rows=rows, timing=timing)
+        return self.result_to_host()

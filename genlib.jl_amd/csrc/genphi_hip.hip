@@ -1,0 +1,611 @@
+// genphi_hip.hip -- gfx950 (MI355X / CDNA4) kernels and the C-ABI of the gen.phi hot path.
+//
+// What runs here replaces src/compute.jl:269-303 of the reference (Psi = 1/2 I, the level
+// loop with the recursive per-pair kernel :105-158 under Threads.@threads, Psi = phi).
+//
+// Arithmetic contract: level matrices are Float32 in HBM; each
+// entry is a Float64 sum of <= 4 Float32 loads, grouped exactly as the reference's
+// recursion groups them, scaled by an exact power of two and converted to Float32 once
+// (round-to-nearest-even, subnormals kept).  No fast-math, no contraction.
+//
+// HBM layout of a level matrix (cut of n members): (n + 1) rows x ld floats, ld = multiple
+// of 64 >= n + 1.  Row n and the columns >= n are all zero, so "no parent" is index n and
+// every gather is unconditional.
+//
+// Kernels
+//   level_rows_kernel<HALF=false>  one workgroup per output row: the (<= 2) source rows of
+//       the row's member are staged whole into LDS with 16-byte coalesced loads, then every
+//       output column gathers its (<= 4) terms from LDS and the row is written coalesced.
+//   level_rows_kernel<HALF=true>   for cuts too wide for two whole rows in LDS (> ~20k):
+//       only a window of the B-side (mother) columns is staged; the A-side (father) terms
+//       are read straight from HBM/L2 -- the planner stores the columns sorted by A inside
+//       each window bucket, so those reads are near-coalesced.
+//   level_naive_kernel             one thread per entry, four global gathers (reference
+//       kernel for A/B comparisons; opts.kernel = 1).
+//   colperm_kernel                 proband-order delivery of a final level computed in
+//       locality order (HALF mode only).
+//   No MFMA anywhere: this is a gather-average, HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/genphi.h"
+#include "planner.h"
+
+using genphi::LevelStep;
+using genphi::Plan;
+using genphi::Segment;
+
+// ---------------------------------------------------------------------------------------------
+// device code
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kOrdMask = 0x7fffffff;
+
+// Float64 grouping of the reference recursion.
+//   a = Psi[A_i][A_j]  b = Psi[A_i][B_j]  c = Psi[B_i][A_j]  d = Psi[B_i][B_j]
+//   i climbs first (rank_i > rank_j): (a + b) + (c + d); otherwise (a + c) + (b + d).
+// Halvings are exact, so they are applied once as `scale` (1, 1/2 or 1/4).
+__device__ __forceinline__ float combine(float a, float b, float c, float d, bool i_hi, double scale)
+{
+    const double da = a, db = b, dc = c, dd = d;
+    const double s = i_hi ? ((da + db) + (dc + dd)) : ((da + dc) + (db + dd));
+    return static_cast<float>(s * scale);
+}
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    // consecutive work items on one XCD (blocks b and b+8 share an XCD): rows that share a
+    // source row then hit the same L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+struct LevelArgs {
+    const float *psi;        // previous level matrix
+    float *out;              // this level's matrix (or the shard buffer of the last level)
+    long long ld_prev, ld;
+    int n_prev, n;
+    const int *srcA, *srcB, *ord;   // per member of this cut (storage order)
+    const int *rows;         // work list: storage row ids (n_rows entries)
+    const int *out_rows;     // row of `out` for each work item; nullptr = same as storage row
+    int n_rows;
+    // HALF mode
+    const Segment *segs;
+    const int *b_rel;
+    int n_segs;
+    int lds_row;             // floats per staged row in LDS
+};
+
+template <bool HALF>
+__global__ void __launch_bounds__(1024) level_rows_kernel(const LevelArgs p)
+{
+    extern __shared__ float lds[];
+    float *sA = lds;
+    float *sB = lds + p.lds_row;
+
+    const int w = xcd_remap(blockIdx.x, p.n_rows);
+    const int i = p.rows[w];
+    const long long orow = p.out_rows ? p.out_rows[w] : i;
+    const int Ai = p.srcA[i], Bi = p.srcB[i];
+    const int ord_i_raw = p.ord[i];
+    const bool new_i = ord_i_raw < 0;
+    const int ord_i = ord_i_raw & kOrdMask;
+    const bool hasB = Bi != p.n_prev;              // wave-uniform: dragged / one-parent rows stage one row
+    const float *rowA = p.psi + (long long)Ai * p.ld_prev;
+    const float *rowB = p.psi + (long long)Bi * p.ld_prev;
+    float *orowp = p.out + orow * p.ld;
+    const double sc_i = new_i ? 0.5 : 1.0;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
+    float diag = 0.f;
+    if (new_i) diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(rowA[Bi]));
+
+    if (!HALF) {
+        // ---- stage both source rows whole: columns [0, lds_row) include the zero column ----
+        const int nvec = p.lds_row >> 2;
+        for (int v = tid; v < nvec; v += nt) {
+            reinterpret_cast<float4 *>(sA)[v] = reinterpret_cast<const float4 *>(rowA)[v];
+        }
+        if (hasB) {
+            for (int v = tid; v < nvec; v += nt) {
+                reinterpret_cast<float4 *>(sB)[v] = reinterpret_cast<const float4 *>(rowB)[v];
+            }
+        }
+        __syncthreads();
+        if (hasB) {
+            for (int j = tid; j < p.n; j += nt) {
+                const int Aj = p.srcA[j], Bj = p.srcB[j], oj = p.ord[j];
+                const float a = sA[Aj], b = sA[Bj], c = sB[Aj], d = sB[Bj];
+                const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
+                float v = combine(a, b, c, d, ord_i > (oj & kOrdMask), sc);
+                if (j == i && new_i) v = diag;
+                orowp[j] = v;
+            }
+        } else {
+            for (int j = tid; j < p.n; j += nt) {
+                const int Aj = p.srcA[j], Bj = p.srcB[j], oj = p.ord[j];
+                const float a = sA[Aj], b = sA[Bj];
+                const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
+                float v = combine(a, b, 0.f, 0.f, true, sc);
+                if (j == i && new_i) v = diag;
+                orowp[j] = v;
+            }
+        }
+    } else {
+        int cur_win = -1;
+        for (int s = 0; s < p.n_segs; ++s) {
+            const Segment sg = p.segs[s];
+            if (sg.win_begin != cur_win) {
+                if (cur_win >= 0) __syncthreads();          // everyone done with the old window
+                const int nvec = (sg.win_len + 3) >> 2;     // win_begin is a multiple of 4
+                const float4 *gA = reinterpret_cast<const float4 *>(rowA + sg.win_begin);
+                const float4 *gB = reinterpret_cast<const float4 *>(rowB + sg.win_begin);
+                for (int v = tid; v < nvec; v += nt) reinterpret_cast<float4 *>(sA)[v] = gA[v];
+                if (hasB) for (int v = tid; v < nvec; v += nt) reinterpret_cast<float4 *>(sB)[v] = gB[v];
+                __syncthreads();
+                if (tid == 0) { sA[sg.win_len] = 0.f; sB[sg.win_len] = 0.f; }   // the "none" slot
+                __syncthreads();
+                cur_win = sg.win_begin;
+            }
+            if (hasB) {
+                for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
+                    const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
+                    const float a = rowA[Aj], c = rowB[Aj];
+                    const float b = sA[br], d = sB[br];
+                    const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
+                    float v = combine(a, b, c, d, ord_i > (oj & kOrdMask), sc);
+                    if (j == i && new_i) v = diag;
+                    orowp[j] = v;
+                }
+            } else {
+                for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
+                    const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
+                    const float a = rowA[Aj];
+                    const float b = sA[br];
+                    const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
+                    float v = combine(a, b, 0.f, 0.f, true, sc);
+                    if (j == i && new_i) v = diag;
+                    orowp[j] = v;
+                }
+            }
+        }
+    }
+    // zero columns [n, ld): the "none" column of this level and its pitch padding
+    for (long long j = p.n + tid; j < p.ld; j += nt) orowp[j] = 0.f;
+}
+
+__global__ void level_naive_kernel(const LevelArgs p)
+{
+    const int w = blockIdx.x;                        // grid.y is limited to 65535: rows go on x
+    const long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= p.ld) return;
+    const int i = p.rows[w];
+    const long long orow = p.out_rows ? p.out_rows[w] : i;
+    float v = 0.f;
+    if (j < p.n) {
+        const int Ai = p.srcA[i], Bi = p.srcB[i], oi = p.ord[i];
+        const int Aj = p.srcA[j], Bj = p.srcB[j], oj = p.ord[j];
+        const float *rowA = p.psi + (long long)Ai * p.ld_prev;
+        const float *rowB = p.psi + (long long)Bi * p.ld_prev;
+        if (j == i && oi < 0) {
+            v = static_cast<float>(0.5 + 0.5 * static_cast<double>(rowA[Bi]));
+        } else {
+            const double sc = (oi < 0 ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
+            v = combine(rowA[Aj], rowA[Bj], rowB[Aj], rowB[Bj], (oi & kOrdMask) > (oj & kOrdMask), sc);
+        }
+    }
+    p.out[orow * p.ld + j] = v;
+}
+
+// Psi_1 = 1/2 I over the top founders (src/compute.jl:271-274); buffer pre-zeroed.
+__global__ void half_identity_kernel(float *m, long long ld, int n, const int *out_rows, int n_rows, int row_begin)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    const int r = row_begin + k;                 // matrix row
+    const long long orow = out_rows ? out_rows[k] : r;
+    if (r < n) m[orow * ld + r] = 0.5f;
+}
+
+// out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
+__global__ void colperm_kernel(const float *in, float *out, long long ld, int n, const int *perm)
+{
+    const long long c = (long long)blockIdx.y * blockDim.x + threadIdx.x;
+    const long long k = blockIdx.x;
+    if (c >= ld) return;
+    out[k * ld + c] = c < n ? in[k * ld + perm[c]] : 0.f;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side: plan object, device state, C-ABI
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(GENPHI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct DeviceStep {
+    int *srcA = nullptr, *srcB = nullptr, *ord = nullptr, *work = nullptr, *b_rel = nullptr;
+    Segment *segs = nullptr;
+};
+
+struct genphi_plan {
+    Plan plan;
+    genphi::PlanOptions popt;
+    // device state (created lazily by the first compute)
+    bool on_device = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *idx_blob = nullptr;
+    std::vector<DeviceStep> dsteps;
+    int *d_final_perm = nullptr;
+    int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
+    int64_t shard_cap = 0, shard_r0 = -1, shard_r1 = -1;
+    float *buf[2] = {nullptr, nullptr};
+    size_t buf_floats[2] = {0, 0};
+    float *result = nullptr, *final_tmp = nullptr;
+    size_t result_floats = 0, final_tmp_floats = 0;
+    int64_t res_ld = 0, res_row_begin = 0, res_n_rows = 0;
+    std::vector<hipEvent_t> events;
+};
+
+static void free_device(genphi_plan *p)
+{
+    if (!p->on_device) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->events.clear();
+    (void)hipFree(p->idx_blob);
+    (void)hipFree(p->d_shard_rows);
+    (void)hipFree(p->d_shard_out_rows);
+    (void)hipFree(p->buf[0]);
+    (void)hipFree(p->buf[1]);
+    (void)hipFree(p->result);
+    (void)hipFree(p->final_tmp);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    p->on_device = false;
+}
+
+extern "C" {
+
+const char *genphi_last_error(void) { return g_last_error.c_str(); }
+const char *genphi_version(void) { return "genphi-mi355x 0.1 (gfx950)"; }
+
+int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                       int64_t n_pro, const int64_t *pro_ids, genphi_plan **out)
+{
+    if (!out) return fail(GENPHI_ERR_ARG, "genphi_plan_create: out is NULL");
+    *out = nullptr;
+    genphi_plan *p = new (std::nothrow) genphi_plan();
+    if (!p) return fail(GENPHI_ERR_ALLOC, "out of memory");
+    if (const char *env = std::getenv("GENPHI_LDS_CAP_FLOATS")) {   // test hook: force HALF mode on small inputs
+        const long v = std::atol(env);
+        if (v >= 16) p->popt.lds_cap_floats = static_cast<int32_t>(v);
+    }
+    std::string err;
+    int rc;
+    try {
+        rc = genphi::build_plan(n_ind, ind, father, mother, n_pro, pro_ids, p->popt, p->plan, err);
+    } catch (const std::bad_alloc &) {
+        delete p;
+        return fail(GENPHI_ERR_ALLOC, "out of memory while planning");
+    }
+    if (rc != GENPHI_OK) { delete p; return fail(rc, err); }
+    *out = p;
+    return GENPHI_OK;
+}
+
+int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels, const int64_t **cut_sizes,
+                       const int64_t **both_counts)
+{
+    if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (n_levels) *n_levels = plan->plan.n_levels;
+    if (cut_sizes) *cut_sizes = plan->plan.cut_sizes.data();
+    if (both_counts) *both_counts = plan->plan.both_counts.data();
+    return GENPHI_OK;
+}
+
+int64_t genphi_plan_n_probands(const genphi_plan *plan) { return plan ? plan->plan.n_pro : -1; }
+double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
+
+void genphi_plan_destroy(genphi_plan *plan)
+{
+    if (!plan) return;
+    free_device(plan);
+    delete plan;
+}
+
+}  // extern "C"
+
+// upload the flat index arrays once
+static int upload_plan(genphi_plan *p, int device)
+{
+    if (p->on_device) {
+        if (device >= 0 && device != p->device) free_device(p);
+        else { HIP_TRY(hipSetDevice(p->device)); return GENPHI_OK; }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GENPHI_ERR_DEVICE, "no HIP device available: the gen.phi product path has no CPU fallback");
+    if (device < 0) { HIP_TRY(hipGetDevice(&device)); }
+    if (device >= ndev) return fail(GENPHI_ERR_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    p->device = device;
+    p->on_device = true;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+
+    const Plan &pl = p->plan;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t total = 256;
+    for (const LevelStep &s : pl.steps) {
+        total += 4 * al(s.n * sizeof(int)) + al(s.b_rel.size() * sizeof(int)) + al(s.segs.size() * sizeof(Segment));
+    }
+    total += al(pl.final_perm.size() * sizeof(int));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
+    std::vector<char> host(total, 0);
+    size_t off = 0;
+    auto put = [&](const void *src, size_t bytes) -> char * {
+        char *d = p->idx_blob + off;
+        if (bytes) std::memcpy(host.data() + off, src, bytes);
+        off += al(bytes);
+        return d;
+    };
+    p->dsteps.resize(pl.steps.size());
+    for (size_t k = 0; k < pl.steps.size(); ++k) {
+        const LevelStep &s = pl.steps[k];
+        DeviceStep &d = p->dsteps[k];
+        d.srcA = reinterpret_cast<int *>(put(s.srcA.data(), s.n * sizeof(int)));
+        d.srcB = reinterpret_cast<int *>(put(s.srcB.data(), s.n * sizeof(int)));
+        d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int)));
+        d.work = reinterpret_cast<int *>(put(s.work.data(), s.n * sizeof(int)));
+        d.b_rel = reinterpret_cast<int *>(put(s.b_rel.data(), s.b_rel.size() * sizeof(int)));
+        d.segs = reinterpret_cast<Segment *>(put(s.segs.data(), s.segs.size() * sizeof(Segment)));
+    }
+    p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(p->idx_blob, host.data(), total, hipMemcpyHostToDevice));
+
+    // ping-pong buffers for the intermediate cuts 0..L-2
+    size_t need[2] = {0, 0};
+    for (int c = 0; c + 1 < pl.n_levels; ++c)
+        need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]));
+    for (int b = 0; b < 2; ++b) {
+        if (need[b]) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float))); }
+        p->buf_floats[b] = need[b];
+    }
+    return GENPHI_OK;
+}
+
+static int ensure_floats(float **ptr, size_t *have, size_t need)
+{
+    if (*have >= need && *ptr) return GENPHI_OK;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(float)));
+    *have = need;
+    return GENPHI_OK;
+}
+
+static int block_size_for(int64_t n)
+{
+    if (n <= 512) return 64;
+    if (n <= 4096) return 256;
+    if (n <= 16384) return 512;
+    return 1024;
+}
+
+static int launch_level(genphi_plan *p, int step, const float *psi, float *out, const int *rows,
+                        const int *out_rows, int n_rows, int kernel)
+{
+    const LevelStep &s = p->plan.steps[step];
+    const DeviceStep &d = p->dsteps[step];
+    LevelArgs a;
+    a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld;
+    a.n_prev = static_cast<int>(s.n_prev); a.n = static_cast<int>(s.n);
+    a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord;
+    a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
+    a.segs = d.segs; a.b_rel = d.b_rel; a.n_segs = static_cast<int>(s.segs.size());
+    a.lds_row = 0;
+    if (n_rows <= 0) return GENPHI_OK;
+    if (kernel == 1) {
+        dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
+        hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
+    } else if (!s.half_mode) {
+        a.lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
+        const size_t lds = 2 * static_cast<size_t>(a.lds_row) * sizeof(float);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_rows_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        const int bs = block_size_for(std::max(s.n, s.n_prev));
+        hipLaunchKernelGGL(level_rows_kernel<false>, dim3(n_rows), dim3(bs), lds, p->stream, a);
+    } else {
+        int wmax = 0;
+        for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
+        a.lds_row = (wmax + 4 + 3) / 4 * 4;
+        const size_t lds = 2 * static_cast<size_t>(a.lds_row) * sizeof(float);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_rows_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(level_rows_kernel<true>, dim3(n_rows), dim3(1024), lds, p->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENPHI_OK;
+}
+
+extern "C" {
+
+int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats *stats)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    const Plan &pl = p->plan;
+    const int device = opts ? opts->device : -1;
+    const int kernel = opts ? opts->kernel : 0;
+    const bool timing = opts && opts->timing && stats;
+    int64_t r0 = 0, r1 = pl.n_pro;
+    if (opts && opts->row_end > 0) { r0 = opts->row_begin; r1 = opts->row_end; }
+    if (r0 < 0 || r1 > pl.n_pro || r0 > r1) return fail(GENPHI_ERR_ARG, "row shard out of range");
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n_steps = std::max(pl.n_levels - 1, 0);
+        stats->algorithmic_bytes = pl.algorithmic_bytes;
+        stats->max_cut = pl.max_cut;
+    }
+    p->res_row_begin = r0; p->res_n_rows = r1 - r0;
+    const int L = pl.n_levels;
+    if (L == 0 || r1 == r0) { p->res_ld = 0; return GENPHI_OK; }
+
+    int rc = upload_plan(p, device);
+    if (rc) return rc;
+    const int n_steps = L - 1;
+    if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
+    if (timing) {
+        while (static_cast<int>(p->events.size()) < n_steps + 3) {
+            hipEvent_t e; HIP_TRY(hipEventCreate(&e)); p->events.push_back(e);
+        }
+    }
+
+    const int64_t N = pl.n_pro, ldN = pl.ld[L - 1], n_rows = r1 - r0;
+    rc = ensure_floats(&p->result, &p->result_floats, static_cast<size_t>(n_rows * ldN));
+    if (rc) return rc;
+    p->res_ld = ldN;
+    const bool need_perm = !pl.final_perm.empty();
+    if (need_perm) {
+        rc = ensure_floats(&p->final_tmp, &p->final_tmp_floats, static_cast<size_t>(n_rows * ldN));
+        if (rc) return rc;
+    }
+    // shard row lists for the last step: storage row of proband r, output row r - r0
+    if (n_rows > p->shard_cap) {
+        if (p->d_shard_rows) { HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows)); }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_rows), n_rows * sizeof(int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
+        p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
+    }
+    if (p->shard_r0 != r0 || p->shard_r1 != r1) {
+        // work order of the shard: rows sharing a source row adjacent (same rule as the planner)
+        std::vector<int> rows(n_rows), orows(n_rows);
+        std::vector<std::pair<int, int>> key(n_rows);   // (storage row, out row)
+        for (int64_t k = 0; k < n_rows; ++k) {
+            const int r = static_cast<int>(r0 + k);
+            key[k] = {need_perm ? pl.final_perm[r] : r, static_cast<int>(k)};
+        }
+        if (n_steps > 0) {
+            const LevelStep &s = pl.steps[n_steps - 1];
+            std::stable_sort(key.begin(), key.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+                if (s.srcA[a.first] != s.srcA[b.first]) return s.srcA[a.first] < s.srcA[b.first];
+                return s.srcB[a.first] < s.srcB[b.first];
+            });
+        }
+        for (int64_t k = 0; k < n_rows; ++k) { rows[k] = key[k].first; orows[k] = key[k].second; }
+        HIP_TRY(hipMemcpyAsync(p->d_shard_rows, rows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_shard_out_rows, orows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));      // host vectors go out of scope
+        p->shard_r0 = r0; p->shard_r1 = r1;
+    }
+
+    if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
+    if (n_steps == 0) {
+        // all probands parentless: result = 1/2 I (src/compute.jl:271-274, loop skipped)
+        HIP_TRY(hipMemsetAsync(p->result, 0, static_cast<size_t>(n_rows * ldN) * sizeof(float), p->stream));
+        hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0,
+                           p->stream, p->result, ldN, static_cast<int>(N), p->d_shard_out_rows,
+                           static_cast<int>(n_rows), static_cast<int>(r0));
+        HIP_TRY(hipGetLastError());
+    } else {
+        // Psi_1 = 1/2 I over the top founders
+        const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
+        HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
+        hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
+                           p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
+                           static_cast<int>(n0), 0);
+        HIP_TRY(hipGetLastError());
+        for (int s = 0; s < n_steps; ++s) {
+            const LevelStep &st = pl.steps[s];
+            const float *psi = p->buf[s & 1];
+            const bool last = s == n_steps - 1;
+            if (!last) {
+                float *out = p->buf[(s + 1) & 1];
+                rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel);
+                if (rc) return rc;
+                // the all-zero "none" row of this level
+                HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
+            } else {
+                float *out = need_perm ? p->final_tmp : p->result;
+                rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel);
+                if (rc) return rc;
+                if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
+                if (need_perm) {
+                    dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((ldN + 255) / 256));
+                    hipLaunchKernelGGL(colperm_kernel, grid, dim3(256), 0, p->stream, p->final_tmp, p->result, ldN,
+                                       static_cast<int>(N), p->d_final_perm);
+                    HIP_TRY(hipGetLastError());
+                }
+            }
+            if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
+        }
+    }
+    if (timing && n_steps == 0) HIP_TRY(hipEventRecord(p->events[1], p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (timing) {
+        const int ne = std::max(n_steps, 1);
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->events[0], p->events[ne]));
+        stats->total_ms = ms;
+        for (int s = 0; s < ne; ++s) {
+            HIP_TRY(hipEventElapsedTime(&ms, p->events[s], p->events[s + 1]));
+            stats->level_ms[s] = ms;
+        }
+        stats->final_ms = stats->level_ms[ne - 1];
+        if (n_steps > 0) {
+            HIP_TRY(hipEventElapsedTime(&ms, p->events[n_steps + 1], p->events[n_steps]));
+            stats->perm_ms = ms;
+        }
+        stats->timed = 1;
+    }
+    return GENPHI_OK;
+}
+
+int genphi_result_device(const genphi_plan *p, const float **d_ptr, int64_t *ld, int64_t *row_begin, int64_t *n_rows)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (d_ptr) *d_ptr = p->result;
+    if (ld) *ld = p->res_ld;
+    if (row_begin) *row_begin = p->res_row_begin;
+    if (n_rows) *n_rows = p->res_n_rows;
+    return GENPHI_OK;
+}
+
+int genphi_result_to_host(genphi_plan *p, float *out)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (p->res_n_rows == 0 || p->plan.n_pro == 0) return GENPHI_OK;
+    if (!out) return fail(GENPHI_ERR_ARG, "out is NULL");
+    if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t N = static_cast<size_t>(p->plan.n_pro);
+    HIP_TRY(hipMemcpy2DAsync(out, N * sizeof(float), p->result, static_cast<size_t>(p->res_ld) * sizeof(float),
+                             N * sizeof(float), static_cast<size_t>(p->res_n_rows), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return GENPHI_OK;
+}
+
+int genphi_compute_f32(genphi_plan *p, float *out, const genphi_opts *opts, genphi_stats *stats)
+{
+    int rc = genphi_compute_device(p, opts, stats);
+    if (rc) return rc;
+    return genphi_result_to_host(p, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// planner.h -- host-side level planner of the gen.phi hot path (no HIP here).
+//
+// Turns the rank-ordered pedigree + proband list into a sequence of "level steps".
+// Step s computes the kinship matrix of cut s+1 from the matrix of cut s; what the
+// reference does with IndexedIndividual objects, founder_index and a recursive per-pair
+// kernel (src/compute.jl:105-158, :233-304) becomes flat int32 index arrays:
+//
+//   every member x of cut s+1 has up to two SOURCES in cut s
+//       new, both parents : A = father, B = mother        weight 1/2
+//       new, one parent   : A = that parent, B = none     weight 1/2
+//       new, no parent    : A = none, B = none            weight 1/2 (row/col of zeros)
+//       dragged (x is also in cut s) : A = x itself       weight 1
+//   and   phi[i][j] = w_i * w_j * sum_{p in src(i), q in src(j)} Psi[p][q]
+//   (Float64, grouped as the reference groups it), except the diagonal of a
+//   new individual, which is 1/2 + Psi[A][B]/2.
+//
+// "none" is encoded as index n_prev: every level matrix carries one extra all-zero row
+// and zero columns up to its pitch, so kernels gather unconditionally.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace genphi {
+
+constexpr int32_t kNewFlag = INT32_MIN;     // bit 31 of `ord`: member is new (weight 1/2)
+
+struct Segment {            // HALF-mode column segment (see kernels): columns [col_begin,col_end)
+    int32_t col_begin, col_end;   // of cut s+1 take their B source from LDS window
+    int32_t win_begin, win_len;   // [win_begin, win_begin+win_len) of cut s
+};
+
+struct LevelStep {
+    int64_t n_prev = 0, n = 0;        // |cut s|, |cut s+1|
+    int64_t ld_prev = 0, ld = 0;      // row pitch (floats) of the two level matrices
+    int64_t n_dragged = 0;            // |cut s ∩ cut s+1|  ("both" in the verbose lines)
+    // per member of cut s+1, in this cut's storage order:
+    std::vector<int32_t> srcA, srcB;  // positions in cut s; n_prev = none
+    std::vector<int32_t> ord;         // pedigree rank index (0-based) | kNewFlag
+    std::vector<int32_t> work;        // row processing order (rows sharing srcA adjacent)
+    // HALF mode (n_prev too large for both source rows to sit in LDS whole):
+    bool half_mode = false;
+    std::vector<Segment> segs;
+    std::vector<int32_t> b_rel;       // per column: B source relative to its segment's window; win_len = none
+};
+
+struct Plan {
+    int64_t n_ind = 0;
+    int64_t n_pro = 0;                       // distinct probands = side of the result
+    int32_t n_levels = 0;                    // L (number of cuts)
+    std::vector<int64_t> cut_sizes;          // L entries, top founders first
+    std::vector<int64_t> both_counts;        // L-1 entries
+    std::vector<int64_t> ld;                 // row pitch of each cut's matrix
+    std::vector<LevelStep> steps;            // L-1 entries
+    std::vector<int32_t> final_members;      // rank index of each proband, result order
+    // Final cut is kept in a locality order when its step runs in HALF mode; perm maps
+    // result (proband) position -> storage position.  Empty = storage order is proband order.
+    std::vector<int32_t> final_perm;
+    double algorithmic_bytes = 0.0;          // 4 * sum (n_k^2 + n_{k+1}^2)
+    int64_t max_cut = 0;
+};
+
+struct PlanOptions {
+    int32_t lds_cap_floats = 40448;   // floats of LDS a workgroup may use for staged source rows (2 rows x window)
+    bool allow_half_mode = true;
+};
+
+// Returns 0 or a GENPHI_ERR_* code (see include/genphi.h); message in err.
+int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+               int64_t n_pro, const int64_t *pro_ids, const PlanOptions &opt, Plan &plan,
+               std::string &err);
+
+inline int64_t pitch_for(int64_t n) { return ((n + 1) + 63) / 64 * 64; }
+
+}  // namespace genphi

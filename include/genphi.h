@@ -1,0 +1,123 @@
+/*
+ * genphi.h -- C-ABI of the MI355X-native gen.phi hot path (dense kinship matrix).
+ *
+ * Drop-in boundary.  The reference (GPhMorin/GenLib.jl v0.1.4) has no FFI: its boundary is
+ * the Julia method
+ *     phi(pedigree::Pedigree, probandIDs::Vector{Int} = pro(pedigree);
+ *         verbose::Bool = false, compute::Bool = true)          src/compute.jl:233-304
+ * A Julia shim with that exact signature (genlib.jl_amd/julia/GenLibAMD.jl, see
+ * INTEGRATION.md) flattens the pedigree the way genout does (src/output.jl:24-29, kept at
+ * 64 bit) and `ccall`s the entry points below; tests and bench.py bind the same symbols
+ * through ctypes.  Plain pointers and sizes only; nothing throws across this boundary.
+ *
+ * Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - all arrays are caller-owned; the library copies what it needs and keeps no caller
+ *     pointer after a call returns (Julia: GC.@preserve for the duration of the ccall);
+ *   - individuals are passed in RANK ORDER (iteration order of the reference's Pedigree,
+ *     parents before children, src/create.jl:234-254); parent id 0 = unknown;
+ *   - calls on one plan are blocking and must be serialised by the caller; distinct plans
+ *     may be used concurrently; HIP streams are private to the plan;
+ *   - every function returning int returns GENPHI_OK (0) or an error code; the message is
+ *     available from genphi_last_error() (thread-local).
+ */
+#ifndef GENPHI_H
+#define GENPHI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENPHI_OK               0
+#define GENPHI_ERR_UNKNOWN_ID   1   /* reference: KeyError (OrderedDict lookup, src/create.jl:70 via src/compute.jl:196) */
+#define GENPHI_ERR_ORDER        2   /* parent listed after its child: KeyError in _finalize_pedigree, src/create.jl:240-241 */
+#define GENPHI_ERR_DUPLICATE_ID 3
+#define GENPHI_ERR_ALLOC        4
+#define GENPHI_ERR_DEVICE       5   /* no usable GPU / HIP failure: the product has NO CPU fallback */
+#define GENPHI_ERR_ARG          6
+
+typedef struct genphi_plan genphi_plan;
+
+typedef struct genphi_opts {
+    int32_t device;        /* HIP device ordinal; -1 = current device                      */
+    int32_t kernel;        /* 0 = default (LDS-staged rows); 1 = naive per-entry gather     */
+    int64_t row_begin;     /* final-level row shard [row_begin,row_end) in proband order;   */
+    int64_t row_end;       /*   row_end <= 0 means "all rows" (multi-GPU: one shard/rank)   */
+    int32_t timing;        /* !=0: record per-level HIP-event timings into genphi_stats     */
+    int32_t reserved;
+} genphi_opts;
+
+#define GENPHI_MAX_STAT_LEVELS 1024
+typedef struct genphi_stats {
+    int32_t n_steps;                 /* level steps run (L-1)                               */
+    int32_t timed;                   /* 1 if the ms fields below were measured              */
+    double  total_ms;                /* first level kernel start -> last kernel end (HIP events on the plan's stream) */
+    double  final_ms;                /* the last level step (+ proband-order pass) alone    */
+    double  perm_ms;                 /* of which: the proband-order column pass (0 if none)  */
+    double  algorithmic_bytes;       /* 4 * sum_k (n_k^2 + n_{k+1}^2), SURVEY.md 8(d)       */
+    int64_t max_cut;                 /* largest cut size                                    */
+    float   level_ms[GENPHI_MAX_STAT_LEVELS]; /* per level step (first n_steps entries)     */
+} genphi_stats;
+
+/* Replaces the host prologue of phi(): levelisation by parent steps and the cut sets
+ * (src/compute.jl:236-251, helper _previous_generation :193-207), plus the index copy
+ * (_index_pedigree :165-186, founder_index assignment :287-289) in flat, device-ready form.
+ * Pure host work: succeeds without a GPU.
+ *   n_ind, ind/father/mother : the pedigree in rank order (0 = unknown parent)
+ *   n_pro, pro_ids           : probandIDs (duplicates collapse, as `∩` does at :251)        */
+int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
+                       const int64_t *mother, int64_t n_pro, const int64_t *pro_ids,
+                       genphi_plan **out);
+
+/* Level description for the "Step i of n: a founders, b probands, c both." lines
+ * (src/compute.jl:253-262 and :280-285).  cut_sizes has *n_levels entries (top founders
+ * first, probands last), both_counts has *n_levels-1.  Pointers stay valid until
+ * genphi_plan_destroy.                                                                      */
+int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels,
+                       const int64_t **cut_sizes, const int64_t **both_counts);
+
+/* Number of distinct probands N (rows/columns of the result, proband first-occurrence order). */
+int64_t genphi_plan_n_probands(const genphi_plan *plan);
+
+/* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
+double genphi_plan_algorithmic_bytes(const genphi_plan *plan);
+
+/* Replaces src/compute.jl:269-303 (Psi = 1/2 I, the level loop with the per-pair kernel
+ * :105-158 under Threads.@threads :291-299, Psi = phi).  Runs on the GPU; the result is
+ * left resident in HBM inside the plan (Float32, N x N, proband order, row pitch
+ * genphi_result_ld floats).  Float32 storage per level, Float64 accumulation, one RN
+ * Float64->Float32 conversion per entry per level: bit-identical to the reference.
+ * opts and stats may be NULL.                                                                */
+int genphi_compute_device(genphi_plan *plan, const genphi_opts *opts, genphi_stats *stats);
+
+/* Device pointer / row pitch (in floats) / first row and row count of the resident result
+ * of the last genphi_compute_device (the rows of the shard it was asked for).               */
+int genphi_result_device(const genphi_plan *plan, const float **d_ptr, int64_t *ld,
+                         int64_t *row_begin, int64_t *n_rows);
+
+/* Copies the resident rows to host: out is (n_rows x N) dense row-major Float32
+ * (== column-major for the symmetric full matrix, so a Julia Matrix{Float32}(undef,N,N)
+ * can be passed directly when all rows were computed).                                       */
+int genphi_result_to_host(genphi_plan *plan, float *out);
+
+/* Convenience = genphi_compute_device + genphi_result_to_host: what the Julia shim's
+ * phi(...; compute=true) calls.  out: N x N Float32, caller-owned.                           */
+int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,
+                       genphi_stats *stats);
+
+/* Frees host and device memory of the plan (NULL is allowed). */
+void genphi_plan_destroy(genphi_plan *plan);
+
+/* Message of the last error on this thread ("" if none). */
+const char *genphi_last_error(void);
+
+/* Library version string. */
+const char *genphi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENPHI_H */

@@ -1,0 +1,192 @@
+"""ctypes front-end of the CPU oracle (oracle/genphi_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of genphi_oracle.c.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_I64P = C.POINTER(C.c_int64)
+_F32P = C.POINTER(C.c_float)
+
+
+def build():
+    """Compile liboracle.so with gcc (idempotent)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "genphi_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_rank_order.argtypes = [C.c_int64, _I64P, _I64P, _I64P, _I64P]
+        L.oracle_ped_create.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.POINTER(C.c_void_p)]
+        L.oracle_ped_free.argtypes = [C.c_void_p]
+        L.oracle_ped_free.restype = None
+        L.oracle_pro.argtypes = [C.c_void_p, _I64P, C.c_int64]
+        L.oracle_pro.restype = C.c_int64
+        L.oracle_founder.argtypes = [C.c_void_p, _I64P, C.c_int64]
+        L.oracle_founder.restype = C.c_int64
+        L.oracle_phi_pair.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]
+        L.oracle_f.argtypes = [C.c_void_p, C.c_int64, _I64P, _F32P]
+        L.oracle_levels_create.argtypes = [C.c_void_p, C.c_int64, _I64P, C.POINTER(C.c_void_p)]
+        L.oracle_levels_free.argtypes = [C.c_void_p]
+        L.oracle_levels_free.restype = None
+        L.oracle_levels_count.argtypes = [C.c_void_p]
+        L.oracle_levels_count.restype = C.c_int32
+        L.oracle_levels_cut_size.argtypes = [C.c_void_p, C.c_int32]
+        L.oracle_levels_cut_size.restype = C.c_int64
+        L.oracle_levels_both.argtypes = [C.c_void_p, C.c_int32]
+        L.oracle_levels_both.restype = C.c_int64
+        L.oracle_levels_cut_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _I64P]
+        L.oracle_levels_cut_ids.restype = None
+        L.oracle_phi_compute.argtypes = [C.c_void_p, C.c_void_p, _F32P, C.c_int32, _I64P]
+        L.oracle_phi_mean.argtypes = [_F32P, C.c_int64]
+        L.oracle_phi_mean.restype = C.c_float
+        L.oracle_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_I64P)
+
+
+class OracleError(KeyError):
+    pass
+
+
+def read_tsv(path):
+    """src/create.jl:161-189: skip the header line, whitespace-split, four Ints per row."""
+    rows = np.loadtxt(path, dtype=np.int64, skiprows=1, ndmin=2)
+    return rows[:, 0].copy(), rows[:, 1].copy(), rows[:, 2].copy(), rows[:, 3].copy()
+
+
+class Pedigree:
+    """Rank-ordered pedigree as gen.genealogy(...; sort=true) builds it."""
+
+    def __init__(self, ind, father, mother, sort=True):
+        L = lib()
+        ind, father, mother = _i64(ind), _i64(father), _i64(mother)
+        n = len(ind)
+        if sort:
+            order = np.empty(n, dtype=np.int64)
+            rc = L.oracle_rank_order(n, _p(ind), _p(father), _p(mother), _p(order))
+            if rc:
+                raise OracleError(f"oracle_rank_order rc={rc}")
+            ind, father, mother = ind[order], father[order], mother[order]
+        self.ind, self.father, self.mother = _i64(ind), _i64(father), _i64(mother)
+        self.n = n
+        h = C.c_void_p()
+        rc = L.oracle_ped_create(n, _p(self.ind), _p(self.father), _p(self.mother), C.byref(h))
+        if rc:
+            raise OracleError(f"oracle_ped_create rc={rc}")
+        self._h = h
+
+    @classmethod
+    def from_file(cls, path, sort=True):
+        ind, father, mother, _ = read_tsv(path)
+        return cls(ind, father, mother, sort=sort)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().oracle_ped_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def pro(self):
+        out = np.empty(self.n, dtype=np.int64)
+        k = lib().oracle_pro(self._h, _p(out), self.n)
+        return out[:k].copy()
+
+    def founder(self):
+        out = np.empty(self.n, dtype=np.int64)
+        k = lib().oracle_founder(self._h, _p(out), self.n)
+        return out[:k].copy()
+
+    def phi_pair(self, i, j):
+        v = C.c_double()
+        rc = lib().oracle_phi_pair(self._h, int(i), int(j), C.byref(v))
+        if rc:
+            raise OracleError(f"unknown ID ({i}, {j})")
+        return v.value
+
+    def f(self, ids):
+        ids = _i64(ids)
+        out = np.empty(len(ids), dtype=np.float32)
+        rc = lib().oracle_f(self._h, len(ids), _p(ids), out.ctypes.data_as(_F32P))
+        if rc:
+            raise OracleError("unknown ID")
+        return out
+
+    def levels(self, pro=None):
+        """(cut_sizes, both_counts, cut_id_lists) as src/compute.jl:236-262 derives them."""
+        L = lib()
+        pro = self.pro() if pro is None else _i64(pro)
+        lv = C.c_void_p()
+        rc = L.oracle_levels_create(self._h, len(pro), _p(pro), C.byref(lv))
+        if rc:
+            raise OracleError("unknown proband ID")
+        try:
+            nl = L.oracle_levels_count(lv)
+            sizes = [L.oracle_levels_cut_size(lv, k) for k in range(nl)]
+            both = [L.oracle_levels_both(lv, k) for k in range(nl - 1)]
+            cuts = []
+            for k in range(nl):
+                ids = np.empty(sizes[k], dtype=np.int64)
+                L.oracle_levels_cut_ids(self._h, lv, k, _p(ids))
+                cuts.append(ids)
+        finally:
+            L.oracle_levels_free(lv)
+        return sizes, both, cuts
+
+    def phi(self, pro=None, stop_after_levels=0):
+        """gen.phi(ped, pro): Matrix{Float32}; with stop_after_levels>0 returns
+        (None, entries_evaluated) after that many level steps (bench sampling)."""
+        L = lib()
+        pro = self.pro() if pro is None else _i64(pro)
+        lv = C.c_void_p()
+        rc = L.oracle_levels_create(self._h, len(pro), _p(pro), C.byref(lv))
+        if rc:
+            raise OracleError("unknown proband ID")
+        try:
+            nl = L.oracle_levels_count(lv)
+            n = L.oracle_levels_cut_size(lv, nl - 1)
+            done = C.c_int64(0)
+            if stop_after_levels > 0 and stop_after_levels < nl - 1:
+                rc = L.oracle_phi_compute(self._h, lv, None, stop_after_levels, C.byref(done))
+                if rc:
+                    raise MemoryError("oracle_phi_compute")
+                return None, done.value
+            out = np.empty((n, n), dtype=np.float32)
+            rc = L.oracle_phi_compute(self._h, lv, out.ctypes.data_as(_F32P), 0, C.byref(done))
+            if rc:
+                raise MemoryError("oracle_phi_compute")
+        finally:
+            L.oracle_levels_free(lv)
+        return out
+
+
+def phi_mean(phi):
+    phi = np.ascontiguousarray(phi, dtype=np.float32)
+    return float(lib().oracle_phi_mean(phi.ctypes.data_as(_F32P), phi.shape[0]))
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())

@@ -1,0 +1,137 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol of
+include/genphi.h, the planner's levelisation equals the oracle's literal restatement of
+src/compute.jl:236-262, the Python mirror of genealogy/pro/founder equals the oracle's, and
+the error behaviour matches the reference (KeyError).  No compute calls: no GPU here."""
+import ctypes
+import io
+import os
+import re
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_library_exports_every_declared_symbol(gen):
+    from genlib_jl_amd import _capi
+    header = open(os.path.join(ROOT, "include", "genphi.h")).read()
+    declared = set(re.findall(r"\b(genphi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"genphi_opts", "genphi_stats", "genphi_plan"}
+    assert declared == set(_capi.EXPORTED_SYMBOLS)
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in _capi.lib().genphi_version()
+
+
+def _load(gen, path):
+    return gen.genealogy(path)
+
+
+@pytest.mark.parametrize("name", ["geneaJi.csv", "genea140.csv"])
+def test_genealogy_pro_founder_match_oracle(gen, oracle, name):
+    path = os.path.join(HERE, "golden", name)
+    ped = _load(gen, path)
+    oped = oracle.Pedigree.from_file(path)
+    assert np.array_equal(ped.ind, oped.ind)            # same rank order (stable depth sort)
+    assert np.array_equal(ped.father, oped.father) and np.array_equal(ped.mother, oped.mother)
+    assert np.array_equal(gen.pro(ped), oped.pro())
+    assert np.array_equal(gen.founder(ped), oped.founder())
+
+
+def _check_levels(gen, oracle, ind, fa, mo, sex, pro):
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    oped = oracle.Pedigree(ind, fa, mo)
+    assert np.array_equal(ped.ind, oped.ind)
+    pl = gen.plan(ped, pro)
+    sizes, both = pl.levels()
+    osizes, oboth, ocuts = oped.levels(pro)
+    assert sizes == osizes and both == oboth
+    assert pl.n_probands == len(ocuts[-1])
+    assert pl.algorithmic_bytes == 4.0 * sum(a * a + b * b for a, b in zip(sizes[:-1], sizes[1:]))
+    pl.close()
+
+
+def test_levels_match_oracle_bundled(gen, oracle):
+    for name in ["geneaJi.csv", "genea140.csv"]:
+        ind, fa, mo, sex = oracle.read_tsv(os.path.join(HERE, "golden", name))
+        _check_levels(gen, oracle, ind, fa, mo, sex, None if True else None)
+    ind, fa, mo, sex = oracle.read_tsv(os.path.join(HERE, "golden", "genea140.csv"))
+    ped = gen.genealogy(os.path.join(HERE, "golden", "genea140.csv"))
+    pro = gen.pro(ped)
+    # explicit proband subsets, shuffled order, with duplicates and a non-leaf proband
+    rng = np.random.default_rng(1)
+    sub = rng.permutation(pro)[:17].tolist()
+    sub = sub + [sub[0], int(ped.father[np.flatnonzero(ped.ind == sub[1])[0]])]
+    _check_levels(gen, oracle, ind, fa, mo, sex, np.array(sub))
+
+
+def test_levels_match_oracle_synthetic(gen, oracle):
+    from genlib_jl_amd import synth
+    for args, kw in [((3000, 300, 12), dict(skip_permille=50)), ((5000, 500, 8), dict(skip_permille=0)),
+                     ((2000, 100, 25), dict(skip_permille=200, seed=7))]:
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        _check_levels(gen, oracle, ind, fa, mo, sex, pro)
+    ind, fa, mo, sex, pro = synth.deep_inbred(60, 20, 3)
+    _check_levels(gen, oracle, ind, fa, mo, sex, pro)
+    ind, fa, mo, sex, pro = synth.chain_two_lines(40)
+    _check_levels(gen, oracle, ind, fa, mo, sex, pro)
+
+
+def test_verbose_lines_and_compute_false(gen):
+    ped = gen.genealogy(gen.geneaJi)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert gen.phi(ped, compute=False) is None       # src/compute.jl:264-266
+    lines = buf.getvalue().splitlines()
+    assert lines[0] == "Step 1 of 7: 2 founders, 4 probands, 2 both."      # format of :257-260
+    assert lines[-1] == "Step 7 of 7: 4 founders, 3 probands, 0 both."
+    assert len(lines) == 7
+
+
+def test_error_behaviour(gen):
+    ped = gen.genealogy(gen.geneaJi)
+    with pytest.raises(KeyError):                        # unknown proband: KeyError (create.jl:70)
+        gen.plan(ped, [1, 12345])
+    with pytest.raises(KeyError):                        # parent listed after child, sort=false
+        gen.genealogy({"ind": [1, 2], "father": [2, 0], "mother": [0, 0], "sex": [1, 1]}, sort=False)
+    from genlib_jl_amd import _capi
+    with pytest.raises(KeyError):                        # same through the raw C-ABI
+        _capi.PhiPlan([1, 2], [2, 0], [0, 0], [1])
+    with pytest.raises(ValueError):
+        _capi.PhiPlan([1, 1], [0, 0], [0, 0], [1])
+    # duplicates collapse, order = first occurrence
+    pl = gen.plan(ped, [29, 1, 29, 2, 1])
+    assert pl.n_probands == 3
+    pl.close()
+    # no probands: empty plan
+    pl = gen.plan(ped, [])
+    assert pl.levels() == ([], []) and pl.n_probands == 0
+    pl.close()
+
+
+def test_no_gpu_means_loud_failure(gen):
+    """The product path has no CPU fallback: without a device compute must raise."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ped = gen.genealogy(gen.geneaJi)
+    with pytest.raises(gen.GenphiDeviceError):
+        gen.phi(ped)
+
+
+def test_synthetic_generator_is_deterministic(gen):
+    from genlib_jl_amd import synth
+    a = synth.random_mating(1000, 100, 10)
+    b = synth.random_mating(1000, 100, 10)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # SplitMix64 known answers (seed 1234567: first outputs of the published generator)
+    out = synth.splitmix64(1234567, np.arange(3))
+    assert [int(v) for v in out] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+    ind, fa, mo, sex, pro = a
+    assert np.all(fa < ind) and np.all(mo < ind) and len(pro) == 100
+    assert np.all(sex[fa[fa > 0] - 1] == 1) and np.all(sex[mo[mo > 0] - 1] == 2)

@@ -1,0 +1,77 @@
+"""Pins the CPU oracle (oracle/genphi_oracle.c) to every value the reference's own tests
+hold for the gen.phi path (test/runtests.jl:41-60, on data/geneaJi.csv) and to the
+survey-derived genea140 values."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_pinned.json")))
+
+
+def test_geneaJi_reference_pinned(oracle):
+    g = GOLD["geneaJi"]
+    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "geneaJi.csv"))
+    assert ped.pro().tolist() == g["pro"]                                  # runtests.jl:41
+    assert ped.founder().tolist() == g["founder"]                          # :42
+    assert ped.f([1]).tolist() == [g["f_1"]]                               # :47
+    assert ped.f([17]).tolist() == [g["f_17"]]                             # :48
+    assert ped.phi_pair(1, 2) == g["phi_pair_1_2"]                         # :49
+    phi = ped.phi()
+    assert phi.dtype == np.float32
+    assert np.array_equal(phi, np.array(g["phi"], dtype=np.float32))       # :50-52 (exact ==)
+    assert oracle.phi_mean(phi) == g["phiMean"]                            # :53
+    assert ped.phi_pair(17, 19) == g["phi_pair_founders_17_19"]            # :58-60
+    sizes, both, _ = ped.levels()
+    assert sizes == g["cut_sizes_survey"] and both == g["both_survey"]
+
+
+def test_genea140_survey_derived(oracle):
+    g = GOLD["genea140_survey_derived"]
+    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "genea140.csv"))
+    assert ped.n == g["n_individuals"]
+    pro = ped.pro()
+    assert len(pro) == g["n_probands"]
+    assert pro[:5].tolist() == g["pro_first5"] and pro[-3:].tolist() == g["pro_last3"]
+    sizes, both, _ = ped.levels()
+    assert sizes == g["cut_sizes"] and both == g["both"]
+    assert sum(a * a + b * b for a, b in zip(sizes[:-1], sizes[1:])) == g["sum_entries_sq"]
+    assert ped.phi_pair(10033, 113470) == g["pair_sibs_10033_113470"]
+    phi = ped.phi()
+    assert np.array_equal(phi, phi.T)
+    p64 = phi.astype(np.float64)
+    assert float(p64.sum()) == g["sum_all"]
+    assert float(np.trace(p64)) == g["trace"]
+    assert int(np.count_nonzero(phi)) == g["nonzeros"]
+    assert float(phi.diagonal().min()) == g["diag_min"] and float(phi.diagonal().max()) == g["diag_max"]
+    idx = {int(v): k for k, v in enumerate(pro)}
+    for key, hx in g["samples_hex"].items():
+        a, b = (int(t) for t in key.split(","))
+        assert float(phi[idx[a], idx[b]]) == float.fromhex(hx), key
+    # the committed oracle-derived fixture is what the oracle still produces
+    fix = np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy"))
+    assert np.array_equal(phi, fix)
+    # independent check of the level sweep: exact Float64 pairwise Karigl agrees to the
+    # Float32-per-level rounding (<= ~3e-8), on a sample of pairs
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        a, b = rng.integers(0, len(pro), 2)
+        assert abs(ped.phi_pair(pro[a], pro[b]) - float(phi[a, b])) <= 4e-8
+
+
+def test_oracle_edge_cases(oracle):
+    # all probands parentless -> 1/2 I (src/compute.jl:271-274, loop skipped)
+    ped = oracle.Pedigree([1, 2, 3], [0, 0, 0], [0, 0, 0])
+    assert np.array_equal(ped.phi([1, 2, 3]), 0.5 * np.eye(3, dtype=np.float32))
+    # proband that is an ancestor of another proband; one-parent individual; duplicates collapse
+    ind, fa, mo = [1, 2, 3, 4, 5], [0, 0, 1, 3, 0], [0, 0, 2, 0, 4]
+    ped = oracle.Pedigree(ind, fa, mo)
+    phi = ped.phi([5, 3, 5, 1])
+    assert phi.shape == (3, 3)
+    for a, x in enumerate([5, 3, 1]):
+        for b, y in enumerate([5, 3, 1]):
+            assert abs(ped.phi_pair(x, y) - float(phi[a, b])) < 1e-12
+    import pytest
+    with pytest.raises(KeyError):
+        ped.phi([99])
