@@ -74,17 +74,20 @@ def cpu_baseline(ped, pro, sizes, budget_s=20.0):
         t = time.perf_counter() - t0
         return {"value": n_pro * n_pro / t, "unit": "proband-pairs/s", "cores": O.num_threads(), "kind": "port",
                 "sample": "the whole workload, one run of the C/OpenMP oracle"}
-    rate1 = done1 / max(t1, 1e-9)
-    k, acc = 1, 0
-    for n in sizes[1:-1]:
-        acc += n * (n + 1) // 2
-        if acc / rate1 > budget_s:
-            break
-        k += 1
-    k = max(1, min(k, len(sizes) - 2))
-    t0 = time.perf_counter()
-    _, done = oped.phi(pro, stop_after_levels=k)
-    t = time.perf_counter() - t0
+    k, t, done = 1, t1, done1
+    while k < len(sizes) - 2 and t < budget_s / 3:
+        # grow the sample geometrically in evaluations until it costs a few seconds
+        target = max(done * 3, 1)
+        acc, k2 = 0, 0
+        for n in sizes[1:-1]:
+            acc += n * (n + 1) // 2
+            k2 += 1
+            if acc >= target:
+                break
+        k = max(k + 1, min(k2, len(sizes) - 2))
+        t0 = time.perf_counter()
+        _, done = oped.phi(pro, stop_after_levels=k)
+        t = time.perf_counter() - t0
     rate = done / t
     t_est = evals_total / rate
     return {"value": n_pro * n_pro / t_est, "unit": "proband-pairs/s", "cores": O.num_threads(), "kind": "port",
@@ -183,7 +186,9 @@ def main():
                        "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes / 1e9,
                        "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
                        "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,
-                       "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None},
+                       "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
+                       "level_ms": [round(float(x), 4) for x in lvl] if len(lvl) <= 64 else None,
+                       "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
             "roofline": {"bound": "hbm", "kernel": "level_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),

@@ -38,7 +38,7 @@ class GenphiStats(C.Structure):
 
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands",
+    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode",
     "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_compute_f32", "genphi_plan_destroy", "genphi_last_error",
     "genphi_version",
@@ -69,6 +69,8 @@ def lib():
         L.genphi_plan_levels.restype = C.c_int
         L.genphi_plan_n_probands.argtypes = [C.c_void_p]
         L.genphi_plan_n_probands.restype = C.c_int64
+        L.genphi_plan_step_mode.argtypes = [C.c_void_p, C.c_int32]
+        L.genphi_plan_step_mode.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -149,6 +151,11 @@ class PhiPlan:
             _raise(rc)
         n = nl.value
         return [int(cs[k]) for k in range(n)], [int(bc[k]) for k in range(max(n - 1, 0))]
+
+    def step_modes(self):
+        """Kernel variant per level step: 0 FULL, 1 SPLIT, 2 HALF."""
+        n = len(self.levels()[0]) - 1
+        return [int(lib().genphi_plan_step_mode(self._h, k)) for k in range(max(n, 0))]
 
     def _opts(self, device, kernel, rows, timing):
         o = GenphiOpts()

@@ -13,13 +13,15 @@
 // every gather is unconditional.
 //
 // Kernels
-//   level_rows_kernel<HALF=false>  one workgroup per output row: the (<= 2) source rows of
-//       the row's member are staged whole into LDS with 16-byte coalesced loads, then every
-//       output column gathers its (<= 4) terms from LDS and the row is written coalesced.
-//   level_rows_kernel<HALF=true>   for cuts too wide for two whole rows in LDS (> ~20k):
-//       only a window of the B-side (mother) columns is staged; the A-side (father) terms
-//       are read straight from HBM/L2 -- the planner stores the columns sorted by A inside
-//       each window bucket, so those reads are near-coalesced.
+//   level_full_kernel   one workgroup per output row: the (<= 2) source rows of the row's
+//       member are staged whole into LDS with 16-byte coalesced loads, then every output
+//       column gathers its (<= 4) terms from LDS and the row is written coalesced.
+//   level_split_kernel  cuts of ~20k..40k members (two rows no longer fit in 160 KB of LDS):
+//       row A is staged, the A-row terms of every column go to registers, row B is staged
+//       into the same buffer, the B-row terms are gathered, combined and the row written.
+//   level_half_kernel   fallback above ~40k members: only a window of the B-side (mother)
+//       columns is staged; the A-side (father) terms are read straight from HBM/L2 -- the
+//       planner stores the columns sorted by A inside each window bucket.
 //   level_naive_kernel             one thread per entry, four global gathers (reference
 //       kernel for A/B comparisons; opts.kernel = 1).
 //   colperm_kernel                 proband-order delivery of a final level computed in
@@ -54,9 +56,19 @@ constexpr int kOrdMask = 0x7fffffff;
 // Halvings are exact, so they are applied once as `scale` (1, 1/2 or 1/4).
 __device__ __forceinline__ float combine(float a, float b, float c, float d, bool i_hi, double scale)
 {
-    const double da = a, db = b, dc = c, dd = d;
-    const double s = i_hi ? ((da + db) + (dc + dd)) : ((da + dc) + (db + dd));
+    const float x = i_hi ? b : c, y = i_hi ? c : b;      // swap the middle terms, not the sums
+    const double s = (static_cast<double>(a) + static_cast<double>(x)) +
+                     (static_cast<double>(y) + static_cast<double>(d));
     return static_cast<float>(s * scale);
+}
+
+// same, with the exact power-of-two weight given as an exponent (0, -1 or -2)
+__device__ __forceinline__ float combine_e(float a, float b, float c, float d, bool i_hi, int e)
+{
+    const float x = i_hi ? b : c, y = i_hi ? c : b;
+    const double s = (static_cast<double>(a) + static_cast<double>(x)) +
+                     (static_cast<double>(y) + static_cast<double>(d));
+    return static_cast<float>(__builtin_ldexp(s, e));
 }
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg)
@@ -73,6 +85,7 @@ struct LevelArgs {
     long long ld_prev, ld;
     int n_prev, n;
     const int *srcA, *srcB, *ord;   // per member of this cut (storage order)
+    const unsigned *pk;      // srcA | srcB << 16 (FULL / SPLIT modes: n_prev < 65536)
     const int *rows;         // work list: storage row ids (n_rows entries)
     const int *out_rows;     // row of `out` for each work item; nullptr = same as storage row
     int n_rows;
@@ -81,105 +94,317 @@ struct LevelArgs {
     const int *b_rel;
     int n_segs;
     int lds_row;             // floats per staged row in LDS
+    int chunk_cols;          // SPLIT: columns per chunk (multiple of blockDim)
+    int n_chunks;            // SPLIT: column chunks per row (work item = row x chunk)
 };
 
-template <bool HALF>
-__global__ void __launch_bounds__(1024) level_rows_kernel(const LevelArgs p)
+// ---- shared pieces of the row kernels --------------------------------------------------------
+struct RowCtx {
+    int i, Ai, Bi, ord_i;
+    bool new_i, hasB;
+    const float *rowA, *rowB;
+    float *orowp;
+    double sc_i;
+    float diag;
+};
+
+__device__ __forceinline__ RowCtx row_setup(const LevelArgs &p)
+{
+    RowCtx r;
+    const int w = xcd_remap(blockIdx.x, p.n_rows);
+    r.i = p.rows[w];
+    const long long orow = p.out_rows ? p.out_rows[w] : r.i;
+    r.Ai = p.srcA[r.i]; r.Bi = p.srcB[r.i];
+    const int o = p.ord[r.i];
+    r.new_i = o < 0;
+    r.ord_i = o & kOrdMask;
+    r.hasB = r.Bi != p.n_prev;                     // workgroup-uniform: dragged / one-parent rows stage one row
+    r.rowA = p.psi + (long long)r.Ai * p.ld_prev;
+    r.rowB = p.psi + (long long)r.Bi * p.ld_prev;
+    r.orowp = p.out + orow * p.ld;
+    r.sc_i = r.new_i ? 0.5 : 1.0;
+    // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
+    r.diag = 0.f;
+    if (r.new_i) r.diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(r.rowA[r.Bi]));
+    return r;
+}
+
+// global -> LDS copy of nvec float4, all loads of a batch issued before the first LDS write
+template <int BATCH>
+__device__ __forceinline__ void stage_row(float *s, const float *g, int nvec, int tid, int nt)
+{
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *s4 = reinterpret_cast<float4 *>(s);
+    for (int base = tid; base < nvec; base += BATCH * nt) {
+        // unconditional (clamped) loads and stores: a per-element guard would push r[] to scratch
+        float4 r[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) r[k] = g4[min(base + k * nt, nvec - 1)];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) s4[min(base + k * nt, nvec - 1)] = r[k];
+    }
+}
+
+// ---- FULL: both source rows staged whole in LDS; pk[j] = srcA | srcB << 16 -------------------
+template <int U, bool POS_ORD>
+__global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
 {
     extern __shared__ float lds[];
     float *sA = lds;
     float *sB = lds + p.lds_row;
-
-    const int w = xcd_remap(blockIdx.x, p.n_rows);
-    const int i = p.rows[w];
-    const long long orow = p.out_rows ? p.out_rows[w] : i;
-    const int Ai = p.srcA[i], Bi = p.srcB[i];
-    const int ord_i_raw = p.ord[i];
-    const bool new_i = ord_i_raw < 0;
-    const int ord_i = ord_i_raw & kOrdMask;
-    const bool hasB = Bi != p.n_prev;              // wave-uniform: dragged / one-parent rows stage one row
-    const float *rowA = p.psi + (long long)Ai * p.ld_prev;
-    const float *rowB = p.psi + (long long)Bi * p.ld_prev;
-    float *orowp = p.out + orow * p.ld;
-    const double sc_i = new_i ? 0.5 : 1.0;
+    const RowCtx r = row_setup(p);
     const int tid = threadIdx.x, nt = blockDim.x;
-
-    // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
-    float diag = 0.f;
-    if (new_i) diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(rowA[Bi]));
-
-    if (!HALF) {
-        // ---- stage both source rows whole: columns [0, lds_row) include the zero column ----
-        const int nvec = p.lds_row >> 2;
-        for (int v = tid; v < nvec; v += nt) {
-            reinterpret_cast<float4 *>(sA)[v] = reinterpret_cast<const float4 *>(rowA)[v];
+    const int nvec = p.lds_row >> 2;               // columns [0, lds_row) include the zero column
+    stage_row<4>(sA, r.rowA, nvec, tid, nt);
+    if (r.hasB) stage_row<4>(sB, r.rowB, nvec, tid, nt);
+    __syncthreads();
+    const int e_ij = (r.new_i ? -1 : 0) - 1;       // every column has weight 1/2 (dragged: A = B = itself)
+    for (int j0 = tid; j0 < p.n; j0 += U * nt) {
+        unsigned pk[U]; int oj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + u * nt, p.n - 1);
+            pk[u] = p.pk[j];
+            oj[u] = POS_ORD ? 0 : p.ord[j];
         }
-        if (hasB) {
-            for (int v = tid; v < nvec; v += nt) {
-                reinterpret_cast<float4 *>(sB)[v] = reinterpret_cast<const float4 *>(rowB)[v];
-            }
-        }
-        __syncthreads();
-        if (hasB) {
-            for (int j = tid; j < p.n; j += nt) {
-                const int Aj = p.srcA[j], Bj = p.srcB[j], oj = p.ord[j];
+        float v[U];
+        if (r.hasB) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int Aj = pk[u] & 0xffff, Bj = pk[u] >> 16;
                 const float a = sA[Aj], b = sA[Bj], c = sB[Aj], d = sB[Bj];
-                const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
-                float v = combine(a, b, c, d, ord_i > (oj & kOrdMask), sc);
-                if (j == i && new_i) v = diag;
-                orowp[j] = v;
+                const bool i_hi = POS_ORD ? (j0 + u * nt < r.i) : (r.ord_i > (oj[u] & kOrdMask));
+                v[u] = combine_e(a, b, c, d, i_hi, e_ij);
             }
         } else {
-            for (int j = tid; j < p.n; j += nt) {
-                const int Aj = p.srcA[j], Bj = p.srcB[j], oj = p.ord[j];
-                const float a = sA[Aj], b = sA[Bj];
-                const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
-                float v = combine(a, b, 0.f, 0.f, true, sc);
-                if (j == i && new_i) v = diag;
-                orowp[j] = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int Aj = pk[u] & 0xffff, Bj = pk[u] >> 16;
+                v[u] = combine_e(sA[Aj], sA[Bj], 0.f, 0.f, true, e_ij);
             }
         }
-    } else {
-        int cur_win = -1;
-        for (int s = 0; s < p.n_segs; ++s) {
-            const Segment sg = p.segs[s];
-            if (sg.win_begin != cur_win) {
-                if (cur_win >= 0) __syncthreads();          // everyone done with the old window
-                const int nvec = (sg.win_len + 3) >> 2;     // win_begin is a multiple of 4
-                const float4 *gA = reinterpret_cast<const float4 *>(rowA + sg.win_begin);
-                const float4 *gB = reinterpret_cast<const float4 *>(rowB + sg.win_begin);
-                for (int v = tid; v < nvec; v += nt) reinterpret_cast<float4 *>(sA)[v] = gA[v];
-                if (hasB) for (int v = tid; v < nvec; v += nt) reinterpret_cast<float4 *>(sB)[v] = gB[v];
-                __syncthreads();
-                if (tid == 0) { sA[sg.win_len] = 0.f; sB[sg.win_len] = 0.f; }   // the "none" slot
-                __syncthreads();
-                cur_win = sg.win_begin;
-            }
-            if (hasB) {
-                for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
-                    const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
-                    const float a = rowA[Aj], c = rowB[Aj];
-                    const float b = sA[br], d = sB[br];
-                    const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
-                    float v = combine(a, b, c, d, ord_i > (oj & kOrdMask), sc);
-                    if (j == i && new_i) v = diag;
-                    orowp[j] = v;
-                }
-            } else {
-                for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
-                    const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
-                    const float a = rowA[Aj];
-                    const float b = sA[br];
-                    const double sc = sc_i * (oj < 0 ? 0.5 : 1.0);
-                    float v = combine(a, b, 0.f, 0.f, true, sc);
-                    if (j == i && new_i) v = diag;
-                    orowp[j] = v;
-                }
-            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * nt;
+            if (j < p.n) r.orowp[j] = (j == r.i && r.new_i) ? r.diag : v[u];
         }
     }
     // zero columns [n, ld): the "none" column of this level and its pitch padding
-    for (long long j = p.n + tid; j < p.ld; j += nt) orowp[j] = 0.f;
+    for (long long j = p.n + tid; j < p.ld; j += nt) r.orowp[j] = 0.f;
+}
+
+// ---- SPLIT: one whole source row in LDS at a time (cuts of ~20k..40k members) ----------------
+// Persistent, software-pipelined.  A work item is (output row, column chunk); a workgroup
+// walks its share of the items.  Per item: stage A lands in LDS, the A-row terms (a, b) of
+// the chunk's columns go to registers, stage B lands in the same LDS buffer, the B-row terms
+// are gathered, combined and written.  While a stage is being gathered from LDS the NEXT
+// stage (row B, or the next item's row A) is already in flight from HBM/L2 into registers,
+// so HBM never idles behind the LDS gathers.  Index words are loaded before the prefetch is
+// issued: vmcnt retires in order, so the gathers only wait for the (older) index loads.
+// The workgroups of one XCD walk consecutive items, so the chunks of one row (and rows that
+// share a source row) are staged from that XCD's L2 after the first touch.
+// Columns keep any order (no sorted-column requirement, no proband-order pass).
+//   pk[j] = A_j | B_j << 16; a dragged column is stored as A = B = itself, so EVERY column has
+//   weight 1/2 (x + x is exact).  POS_ORD: new members with both parents appear in rank order
+//   along the storage order, so "row climbs first" is the position test j < i; otherwise the
+//   per-column rank word ord[j] is loaded.
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *sbase, unsigned byte_off)
+{   // uniform base + 32-bit per-lane byte offset => one VGPR of address (saddr form)
+    return *reinterpret_cast<const T *>(static_cast<const char *>(sbase) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_off(void *sbase, unsigned byte_off, T v)
+{
+    *reinterpret_cast<T *>(static_cast<char *>(sbase) + byte_off) = v;
+}
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <int NTHREADS, int CPT, int STG, bool POS_ORD>
+__global__ void __launch_bounds__(NTHREADS) level_split_kernel(const LevelArgs p)
+{
+    extern __shared__ float lds[];
+    constexpr unsigned NT = NTHREADS;
+    float *sR = lds;
+
+    // work split: the workgroups that share an XCD (blockIdx % 8) walk one contiguous slice
+    // of the item list together
+    const int n_items = p.n_rows * p.n_chunks;
+    const int wpx = gridDim.x >> 3;                       // grid is a multiple of 8
+    const int xcd = blockIdx.x & 7;
+    const int q = n_items >> 3, rem = n_items & 7;
+    const int begin = xcd * q + min(xcd, rem);
+    const int len = q + (xcd < rem ? 1 : 0);
+    int t = blockIdx.x >> 3;
+    if (t >= len) return;
+    unsigned tl = threadIdx.x;                            // re-materialised per item (see asm below)
+
+    // Staging registers: STG float4 per thread cover a whole source row.  Loads and LDS
+    // writes are UNCONDITIONAL: level matrices and the LDS buffer are padded so that the
+    // over-read / over-write past the row's end is harmless (a per-element guard makes hipcc
+    // keep the array in scratch and wait on every load).
+    f4_t pre[STG];
+#define load_pre(SRC)                                                                            \
+    do {                                                                                         \
+        const float *src_ = (SRC);                                                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < STG; ++k_)                                       \
+            pre[k_] = ld_off<f4_t>(src_, (tl + k_ * NT) * 16u);                                  \
+    } while (0)
+#define store_pre()                                                                              \
+    do {                                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < STG; ++k_)                                       \
+            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_]; \
+    } while (0)
+    // row A of item `it` (wave-uniform => scalar registers)
+    auto row_a_of = [&](int it) -> const float * {
+        const int w = it / p.n_chunks;
+        const int i = __builtin_amdgcn_readfirstlane(p.rows[w]);
+        const int Ai = __builtin_amdgcn_readfirstlane(p.srcA[i]);
+        return p.psi + (long long)Ai * p.ld_prev;
+    };
+
+    load_pre(row_a_of(begin + t));
+    for (;;) {
+        const bool have_next = t + wpx < len;
+        // ---- this item's context, all wave-uniform ----
+        const int it = begin + t;
+        const int w = it / p.n_chunks;
+        const int chunk = it - w * p.n_chunks;
+        const int ri = __builtin_amdgcn_readfirstlane(p.rows[w]);
+        const int orow = p.out_rows ? __builtin_amdgcn_readfirstlane(p.out_rows[w]) : ri;
+        const int Ai = __builtin_amdgcn_readfirstlane(p.srcA[ri]);
+        const int Bi = __builtin_amdgcn_readfirstlane(p.srcB[ri]);
+        const int oi = __builtin_amdgcn_readfirstlane(p.ord[ri]);
+        const bool new_i = oi < 0;
+        const int ord_i = oi & kOrdMask;
+        const bool hasB = Bi != p.n_prev;
+        const float *rowA = p.psi + (long long)Ai * p.ld_prev;
+        const float *rowB = p.psi + (long long)Bi * p.ld_prev;
+        float *orowp = p.out + (long long)orow * p.ld;
+        const int e_ij = (new_i ? -1 : 0) - 1;           // weight 2^e: row weight times the column's 1/2
+        // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
+        float diag = 0.f;
+        if (new_i) diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(rowA[Bi]));
+        // the next item's row A (prefetched during this item's last stage); resolved here,
+        // where the wave is about to wait for its own staging loads anyway
+        const float *nextA = have_next ? row_a_of(it + wpx) : rowA;
+
+        const unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+        const unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
+        // keep the per-column address arithmetic inside the loop: hoisted out it costs two
+        // VGPRs per column and spills
+        asm volatile("" : "+v"(tl));
+        __builtin_assume(tl < NT);
+        __syncthreads();                                // previous gathers are done with the buffer
+        store_pre();
+        __syncthreads();
+        // index words first (older than the prefetch => the gathers need not wait for it);
+        // the index arrays are padded, so no clamp
+        unsigned pk[CPT];
+        unsigned long long hi_bits = 0;                 // generic layout only: row climbs first
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) pk[k] = ld_off<unsigned>(p.pk, (cb + tl + k * NT) * 4u);
+        if (!POS_ORD) {
+            int oj[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
+            if (hasB) load_pre(rowB);
+            else if (have_next) load_pre(nextA);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                hi_bits |= (unsigned long long)(ord_i > (oj[k] & kOrdMask) ? 1u : 0u) << k;
+        } else {
+            if (hasB) load_pre(rowB);
+            else if (have_next) load_pre(nextA);
+        }
+        float pa[CPT], pb[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { pa[k] = sR[pk[k] & 0xffff]; pb[k] = sR[pk[k] >> 16]; }
+        if (!hasB) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const unsigned j = cb + tl + k * NT;
+                if (j < ce) {
+                    const float v = combine_e(pa[k], pb[k], 0.f, 0.f, true, e_ij);
+                    st_off<float>(orowp, j * 4u, (j == (unsigned)ri && new_i) ? diag : v);
+                }
+            }
+        } else {
+            __syncthreads();
+            store_pre();                                // row B (waits for its loads here)
+            __syncthreads();
+            if (have_next) load_pre(nextA);
+            // forget the LDS / store addresses derived in pass 1 (kept live across the barrier
+            // they cost several VGPRs per column): re-derive them from pk and tl
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) asm volatile("" : "+v"(pk[k]));
+            unsigned tl2 = tl;
+            asm volatile("" : "+v"(tl2));
+            __builtin_assume(tl2 < NT);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const unsigned j = cb + tl2 + k * NT;
+                const float c = sR[pk[k] & 0xffff], d = sR[pk[k] >> 16];
+                if (j < ce) {
+                    const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
+                    const float v = combine_e(pa[k], pb[k], c, d, i_hi, e_ij);
+                    st_off<float>(orowp, j * 4u, (j == (unsigned)ri && new_i) ? diag : v);
+                }
+            }
+        }
+        // zero columns [n, ld): the "none" column of this level and its pitch padding
+        if (chunk == p.n_chunks - 1)
+            for (unsigned j = p.n + tl; j < (unsigned)p.ld; j += NT) orowp[j] = 0.f;
+        if (!have_next) break;
+        t += wpx;
+    }
+#undef load_pre
+#undef store_pre
+}
+
+// ---- HALF: fallback for cuts too wide for one row in LDS (> ~40k members) --------------------
+// A window of the B-side columns is staged; A-side terms are read straight from HBM/L2 (the
+// planner sorts the columns by A inside each window bucket).  Needs colperm for the last level.
+__global__ void __launch_bounds__(1024) level_half_kernel(const LevelArgs p)
+{
+    extern __shared__ float lds[];
+    float *sA = lds;
+    float *sB = lds + p.lds_row;
+    const RowCtx r = row_setup(p);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int cur_win = -1;
+    for (int s = 0; s < p.n_segs; ++s) {
+        const Segment sg = p.segs[s];
+        if (sg.win_begin != cur_win) {
+            if (cur_win >= 0) __syncthreads();          // everyone done with the old window
+            const int nvec = (sg.win_len + 3) >> 2;     // win_begin is a multiple of 4
+            stage_row<4>(sA, r.rowA + sg.win_begin, nvec, tid, nt);
+            if (r.hasB) stage_row<4>(sB, r.rowB + sg.win_begin, nvec, tid, nt);
+            __syncthreads();
+            if (tid == 0) { sA[sg.win_len] = 0.f; sB[sg.win_len] = 0.f; }   // the "none" slot
+            __syncthreads();
+            cur_win = sg.win_begin;
+        }
+        if (r.hasB) {
+            for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
+                const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
+                const float a = r.rowA[Aj], c = r.rowB[Aj];
+                const float b = sA[br], d = sB[br];
+                float v = combine(a, b, c, d, r.ord_i > (oj & kOrdMask), r.sc_i * (oj < 0 ? 0.5 : 1.0));
+                if (j == r.i && r.new_i) v = r.diag;
+                r.orowp[j] = v;
+            }
+        } else {
+            for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
+                const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
+                float v = combine(r.rowA[Aj], sA[br], 0.f, 0.f, true, r.sc_i * (oj < 0 ? 0.5 : 1.0));
+                if (j == r.i && r.new_i) v = r.diag;
+                r.orowp[j] = v;
+            }
+        }
+    }
+    for (long long j = p.n + tid; j < p.ld; j += nt) r.orowp[j] = 0.f;
 }
 
 __global__ void level_naive_kernel(const LevelArgs p)
@@ -240,8 +465,15 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
             return fail(GENPHI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
+// level matrices carry a zeroed tail so that the SPLIT kernel's unconditional staging loads
+// (STG * 1024 float4 per row, <= 160 KB) may run past the last row
+constexpr size_t kTailPadFloats = 64 * 1024;
+// pk / ord are padded so that the unrolled per-thread column loops need no clamp
+constexpr size_t kIdxPad = 32 * 1024;
+
 struct DeviceStep {
     int *srcA = nullptr, *srcB = nullptr, *ord = nullptr, *work = nullptr, *b_rel = nullptr;
+    unsigned *pk = nullptr;
     Segment *segs = nullptr;
 };
 
@@ -251,6 +483,7 @@ struct genphi_plan {
     // device state (created lazily by the first compute)
     bool on_device = false;
     int device = -1;
+    int n_cus = 256;
     hipStream_t stream = nullptr;
     char *idx_blob = nullptr;
     std::vector<DeviceStep> dsteps;
@@ -323,6 +556,11 @@ int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels, const int64_t
 }
 
 int64_t genphi_plan_n_probands(const genphi_plan *plan) { return plan ? plan->plan.n_pro : -1; }
+int genphi_plan_step_mode(const genphi_plan *plan, int32_t step)
+{
+    if (!plan || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size())) return -1;
+    return plan->plan.steps[step].mode;
+}
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
 
 void genphi_plan_destroy(genphi_plan *plan)
@@ -350,21 +588,27 @@ static int upload_plan(genphi_plan *p, int device)
     p->device = device;
     p->on_device = true;
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
+    }
 
     const Plan &pl = p->plan;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t total = 256;
     for (const LevelStep &s : pl.steps) {
-        total += 4 * al(s.n * sizeof(int)) + al(s.b_rel.size() * sizeof(int)) + al(s.segs.size() * sizeof(Segment));
+        total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int)) + al(s.b_rel.size() * sizeof(int)) +
+                 al(s.segs.size() * sizeof(Segment));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
     std::vector<char> host(total, 0);
     size_t off = 0;
-    auto put = [&](const void *src, size_t bytes) -> char * {
+    auto put = [&](const void *src, size_t bytes, size_t pad_bytes = 0) -> char * {
         char *d = p->idx_blob + off;
         if (bytes) std::memcpy(host.data() + off, src, bytes);
-        off += al(bytes);
+        off += al(bytes + pad_bytes);
         return d;
     };
     p->dsteps.resize(pl.steps.size());
@@ -373,8 +617,14 @@ static int upload_plan(genphi_plan *p, int device)
         DeviceStep &d = p->dsteps[k];
         d.srcA = reinterpret_cast<int *>(put(s.srcA.data(), s.n * sizeof(int)));
         d.srcB = reinterpret_cast<int *>(put(s.srcB.data(), s.n * sizeof(int)));
-        d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int)));
+        d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int), kIdxPad * sizeof(int)));
         d.work = reinterpret_cast<int *>(put(s.work.data(), s.n * sizeof(int)));
+        d.pk = reinterpret_cast<unsigned *>(put(s.pk.data(), s.pk.size() * sizeof(unsigned), kIdxPad * sizeof(unsigned)));
+        if (!s.pk.empty()) {      // padding entries point both sources at the zero column
+            unsigned *hp = reinterpret_cast<unsigned *>(host.data() + (reinterpret_cast<char *>(d.pk) - p->idx_blob));
+            const unsigned zero_pk = static_cast<unsigned>(s.n_prev) | (static_cast<unsigned>(s.n_prev) << 16);
+            for (size_t k = s.pk.size(); k < s.pk.size() + kIdxPad; ++k) hp[k] = zero_pk;
+        }
         d.b_rel = reinterpret_cast<int *>(put(s.b_rel.data(), s.b_rel.size() * sizeof(int)));
         d.segs = reinterpret_cast<Segment *>(put(s.segs.data(), s.segs.size() * sizeof(Segment)));
     }
@@ -384,9 +634,12 @@ static int upload_plan(genphi_plan *p, int device)
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
     for (int c = 0; c + 1 < pl.n_levels; ++c)
-        need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]));
+        need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]) + kTailPadFloats);
     for (int b = 0; b < 2; ++b) {
-        if (need[b]) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float))); }
+        if (need[b]) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float)));
+            HIP_TRY(hipMemset(p->buf[b], 0, need[b] * sizeof(float)));
+        }
         p->buf_floats[b] = need[b];
     }
     return GENPHI_OK;
@@ -401,11 +654,26 @@ static int ensure_floats(float **ptr, size_t *have, size_t need)
     return GENPHI_OK;
 }
 
+static hipError_t set_max_lds(const void *fn, size_t bytes)
+{
+    // dynamic LDS above 64 KB has to be opted into per kernel; remember the largest request
+    static std::vector<std::pair<const void *, size_t>> seen;
+    for (auto &e : seen) {
+        if (e.first == fn) {
+            if (e.second >= bytes) return hipSuccess;
+            e.second = bytes;
+            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        }
+    }
+    seen.emplace_back(fn, bytes);
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 static int block_size_for(int64_t n)
 {
     if (n <= 512) return 64;
-    if (n <= 4096) return 256;
-    if (n <= 16384) return 512;
+    if (n <= 2048) return 256;
+    if (n <= 8192) return 512;
     return 1024;
 }
 
@@ -417,29 +685,70 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
     LevelArgs a;
     a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld;
     a.n_prev = static_cast<int>(s.n_prev); a.n = static_cast<int>(s.n);
-    a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord;
+    a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.pk = d.pk;
     a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
     a.segs = d.segs; a.b_rel = d.b_rel; a.n_segs = static_cast<int>(s.segs.size());
-    a.lds_row = 0;
+    a.lds_row = 0; a.chunk_cols = 0;
     if (n_rows <= 0) return GENPHI_OK;
+    const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
     if (kernel == 1) {
         dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
         hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
-    } else if (!s.half_mode) {
-        a.lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
-        const size_t lds = 2 * static_cast<size_t>(a.lds_row) * sizeof(float);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_rows_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    } else if (s.mode == genphi::kModeFull) {
+        a.lds_row = lds_row;
+        const size_t lds = 2 * static_cast<size_t>(lds_row) * sizeof(float);
         const int bs = block_size_for(std::max(s.n, s.n_prev));
-        hipLaunchKernelGGL(level_rows_kernel<false>, dim3(n_rows), dim3(bs), lds, p->stream, a);
+        if (s.pos_ord) {
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, true>), lds));
+            hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows), dim3(bs), lds, p->stream, a);
+        } else {
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, false>), lds));
+            hipLaunchKernelGGL((level_full_kernel<4, false>), dim3(n_rows), dim3(bs), lds, p->stream, a);
+        }
+    } else if (s.mode == genphi::kModeSplit) {
+        a.lds_row = lds_row;
+        constexpr int nt = 1024;
+        const int stg = (lds_row / 4 + nt - 1) / nt;                 // float4 per thread per staged row
+        const int stg_inst = stg <= 6 ? 6 : (stg <= 8 ? 8 : 10);
+        // LDS must also absorb the unconditional over-write past the row's end
+        const size_t lds = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
+        const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
+        const int max_cpt = (s.pos_ord && stg_inst <= 8) ? 26 : 16;  // register budget of the instantiations
+        const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
+        const int cpt = (per_thread + n_chunks - 1) / n_chunks;
+        a.chunk_cols = cpt * nt;
+        a.n_chunks = n_chunks;
+        const long long n_items = static_cast<long long>(n_rows) * n_chunks;
+        const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
+#define GENPHI_LAUNCH_SPLIT2(C, S, O)                                                                \
+        do {                                                                                         \
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_split_kernel<nt, C, S, O>), lds)); \
+            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a); \
+        } while (0)
+#define GENPHI_LAUNCH_SPLIT1(C, O)                                                                   \
+        do {                                                                                         \
+            if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(C, 6, O);                                        \
+            else if (stg_inst == 8) GENPHI_LAUNCH_SPLIT2(C, 8, O);                                   \
+            else GENPHI_LAUNCH_SPLIT2(C, 10, O);                                                     \
+        } while (0)
+        if (s.pos_ord) {
+            if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, true);
+            else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, true);
+            else if (cpt <= 24) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, true); else GENPHI_LAUNCH_SPLIT2(24, 8, true); }
+            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(26, 6, true); else GENPHI_LAUNCH_SPLIT2(26, 8, true); }
+        } else {
+            if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, false);
+            else GENPHI_LAUNCH_SPLIT1(16, false);
+        }
+#undef GENPHI_LAUNCH_SPLIT2
+#undef GENPHI_LAUNCH_SPLIT1
     } else {
         int wmax = 0;
         for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
         a.lds_row = (wmax + 4 + 3) / 4 * 4;
         const size_t lds = 2 * static_cast<size_t>(a.lds_row) * sizeof(float);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_rows_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(level_rows_kernel<true>, dim3(n_rows), dim3(1024), lds, p->stream, a);
+        HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_half_kernel), lds));
+        hipLaunchKernelGGL(level_half_kernel, dim3(n_rows), dim3(1024), lds, p->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return GENPHI_OK;

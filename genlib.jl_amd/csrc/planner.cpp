@@ -132,9 +132,13 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
 
     // x in cut c is "dragged" in step c-1 -> c iff it is also in cut c-1, i.e. tlast[x] > L-1-c
     auto is_dragged = [&](int32_t x, int32_t c) { return tlast[x] > L - 1 - c; };
-    auto step_is_half = [&](int32_t c_prev) {   // step c_prev -> c_prev+1
-        return opt.allow_half_mode && 2 * (plan.cut_sizes[c_prev] + 4) > opt.lds_cap_floats;
+    auto step_mode = [&](int32_t c_prev) {      // step c_prev -> c_prev+1
+        const int64_t lds_row = (plan.cut_sizes[c_prev] + 1 + 3) / 4 * 4;
+        if (2 * lds_row <= opt.lds_cap_floats) return int(kModeFull);
+        if (lds_row <= opt.lds_cap_floats && plan.cut_sizes[c_prev] < 65535) return int(kModeSplit);
+        return int(kModeHalf);
     };
+    auto step_is_half = [&](int32_t c_prev) { return step_mode(c_prev) == kModeHalf; };
 
     // ---- order the cuts top-down and emit the flat index arrays ----------------------------
     std::vector<int32_t> pos_prev(n_ind, -1), pos_cur(n_ind, -1), mark(n_ind, -1);
@@ -173,7 +177,17 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         const bool reorder = (c < L - 1) || in_half;
         std::vector<int32_t> order(n);
         std::iota(order.begin(), order.end(), 0);
-        if (reorder && c > 0) {
+        // FULL / SPLIT steps: [dragged by previous position..., new by rank...] so that the
+        // kernels need no per-column rank word; HALF steps keep their window-bucket order
+        const bool pos_ord = reorder && c > 0 && !in_half && !out_half;
+        if (pos_ord) {
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                const Member &p = mem[a], &q = mem[b];
+                if (p.is_new != q.is_new) return !p.is_new;
+                if (!p.is_new) return p.A < q.A;
+                return p.x < q.x;
+            });
+        } else if (reorder && c > 0) {
             std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
                 const Member &p = mem[a], &q = mem[b];
                 if (p.group != q.group) return p.group < q.group;
@@ -194,7 +208,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             LevelStep &st = plan.steps[c - 1];
             st.n_prev = n_prev; st.n = n;
             st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
-            st.half_mode = in_half;
+            st.mode = step_mode(c - 1);
+            st.pos_ord = pos_ord;
             st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
             int64_t dragged = 0;
             for (int64_t k = 0; k < n; ++k) {
@@ -204,6 +219,30 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                 dragged += m.is_new ? 0 : 1;
             }
             st.n_dragged = dragged;
+            if (st.mode != kModeHalf) {
+                st.pk.resize(n);
+                // column role: a dragged member is stored as A = B = itself, so every column
+                // carries weight 1/2 (x + x is exact) and the kernels need no per-column weight
+                for (int64_t k = 0; k < n; ++k) {
+                    const uint32_t A = static_cast<uint32_t>(st.srcA[k]);
+                    const uint32_t B = (st.ord[k] < 0) ? static_cast<uint32_t>(st.srcB[k]) : A;
+                    st.pk[k] = A | (B << 16);
+                }
+                // position test usable instead of the rank word?  (new members with both
+                // parents must appear in rank order along the storage order)
+                if (!st.pos_ord) {
+                    bool mono = true;
+                    int32_t last = -1;
+                    for (int64_t k = 0; k < n && mono; ++k) {
+                        if (st.ord[k] < 0 && st.srcB[k] != n_prev) {
+                            const int32_t rk = st.ord[k] & INT32_MAX;
+                            if (rk < last) mono = false;
+                            last = rk;
+                        }
+                    }
+                    st.pos_ord = mono;
+                }
+            }
             plan.both_counts[c - 1] = dragged;
             // row processing order: rows with the same A source adjacent in time
             st.work.resize(n);

@@ -25,6 +25,8 @@ namespace genphi {
 
 constexpr int32_t kNewFlag = INT32_MIN;     // bit 31 of `ord`: member is new (weight 1/2)
 
+enum { kModeFull = 0, kModeSplit = 1, kModeHalf = 2 };
+
 struct Segment {            // HALF-mode column segment (see kernels): columns [col_begin,col_end)
     int32_t col_begin, col_end;   // of cut s+1 take their B source from LDS window
     int32_t win_begin, win_len;   // [win_begin, win_begin+win_len) of cut s
@@ -38,9 +40,13 @@ struct LevelStep {
     std::vector<int32_t> srcA, srcB;  // positions in cut s; n_prev = none
     std::vector<int32_t> ord;         // pedigree rank index (0-based) | kNewFlag
     std::vector<int32_t> work;        // row processing order (rows sharing srcA adjacent)
-    // HALF mode (n_prev too large for both source rows to sit in LDS whole):
-    bool half_mode = false;
-    std::vector<Segment> segs;
+    std::vector<uint32_t> pk;         // srcA | srcB << 16 (FULL / SPLIT modes)
+    // kernel mode, by how much of the two source rows fits in LDS:
+    //   FULL  both rows whole; SPLIT one row at a time; HALF a window of the B side (fallback)
+    int mode = 0;
+    bool pos_ord = false;             // cut s+1 is stored [dragged by A..., new by rank...]: kernels
+                                      // derive "new" and the rank comparison from positions
+    std::vector<Segment> segs;        // HALF only
     std::vector<int32_t> b_rel;       // per column: B source relative to its segment's window; win_len = none
 };
 
@@ -62,7 +68,6 @@ struct Plan {
 
 struct PlanOptions {
     int32_t lds_cap_floats = 40448;   // floats of LDS a workgroup may use for staged source rows (2 rows x window)
-    bool allow_half_mode = true;
 };
 
 // Returns 0 or a GENPHI_ERR_* code (see include/genphi.h); message in err.

@@ -82,6 +82,11 @@ int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels,
 /* Number of distinct probands N (rows/columns of the result, proband first-occurrence order). */
 int64_t genphi_plan_n_probands(const genphi_plan *plan);
 
+/* Kernel variant the planner chose for level step `step` (0-based, < n_levels-1):
+ * 0 = FULL (both source rows in LDS), 1 = SPLIT (one row at a time), 2 = HALF (windowed
+ * fallback); -1 on a bad argument.  Diagnostic only (tests assert every variant is covered). */
+int genphi_plan_step_mode(const genphi_plan *plan, int32_t step);
+
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);
 

@@ -114,15 +114,23 @@ def test_edge_cases(gen, oracle):
 
 
 def test_half_mode_forced_small_windows(gen, oracle, monkeypatch):
-    """HALF-mode kernel (B-side window in LDS, A-side direct) + proband-order delivery,
-    forced on small inputs by shrinking the LDS budget; several windows per row."""
+    """SPLIT (one source row in LDS at a time) and HALF (B-side window in LDS, A-side direct,
+    proband-order delivery pass) kernels, forced on small inputs by shrinking the LDS budget;
+    several windows / chunks per row."""
     from genlib_jl_amd import synth
+    modes_seen = set()
     for cap, args, kw in [(2048, (6000, 700, 7), dict(skip_permille=30)),
+                          (1200, (6000, 700, 7), dict(skip_permille=30)),
                           (512, (6000, 700, 7), dict(skip_permille=0)),
                           (256, (3000, 300, 12), dict(skip_permille=100, seed=11))]:
         monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
         ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
-        _assert_equal(_gpu_phi(gen, ind, fa, mo, sex, pro), oracle.Pedigree(ind, fa, mo).phi(pro))
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        pl = gen.plan(ped, pro)
+        modes_seen |= set(pl.step_modes())
+        _assert_equal(pl.compute(), oracle.Pedigree(ind, fa, mo).phi(pro))
+        pl.close()
+    assert modes_seen == {0, 1, 2}          # FULL, SPLIT and HALF kernels all exercised
     monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", "1024")
     ped = gen.genealogy(gen.genea140)
     _assert_equal(gen.phi(ped), np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy")))
