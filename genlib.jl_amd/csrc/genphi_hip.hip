@@ -629,7 +629,8 @@ static int upload_plan(genphi_plan *p, int device)
         d.segs = reinterpret_cast<Segment *>(put(s.segs.data(), s.segs.size() * sizeof(Segment)));
     }
     p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
-    HIP_TRY(hipMemcpy(p->idx_blob, host.data(), total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
 
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
@@ -638,7 +639,9 @@ static int upload_plan(genphi_plan *p, int device)
     for (int b = 0; b < 2; ++b) {
         if (need[b]) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float)));
-            HIP_TRY(hipMemset(p->buf[b], 0, need[b] * sizeof(float)));
+            // on the plan's own stream: hipMemset on the null stream is asynchronous to the host
+            // and unordered with a non-blocking stream, so it could wipe level results later
+            HIP_TRY(hipMemsetAsync(p->buf[b], 0, need[b] * sizeof(float), p->stream));
         }
         p->buf_floats[b] = need[b];
     }
