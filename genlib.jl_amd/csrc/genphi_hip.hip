@@ -95,7 +95,8 @@ struct LevelArgs {
     int n_segs;
     int lds_row;             // floats per staged row in LDS
     int chunk_cols;          // SPLIT: columns per chunk (multiple of blockDim)
-    int n_chunks;            // SPLIT: column chunks per row (work item = row x chunk)
+    int n_chunks;            // SPLIT: column chunks per row (work item = sibling group x chunk)
+    int n_groups;            // SPLIT: sibling groups (runs of equal A source in the work list)
 };
 
 // ---- shared pieces of the row kernels --------------------------------------------------------
@@ -221,8 +222,18 @@ __device__ __forceinline__ void st_off(void *sbase, unsigned byte_off, T v)
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
+// A work item is (sibling group, column chunk): the rows of a group share source row A, which
+// is staged and gathered ONCE; then only row B is staged per child.  desc[w] = (storage row,
+// output row, B source, ord word) of work row w; grp[g] = (first work row, A source), with a
+// terminating entry.  Children with a B source come first in a group.
+//
+// The kernel is ONE flat loop over stages (A stage of an item, then one B stage per child):
+// a single store_pre site and a single load_pre site, so that the staging registers are
+// allocated once -- register pressure is the limiter here, and a spill is fatal to the
+// pipeline (scratch reloads wait on vmcnt(0), i.e. on the prefetch in flight).
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
-__global__ void __launch_bounds__(NTHREADS) level_split_kernel(const LevelArgs p)
+__global__ void __launch_bounds__(NTHREADS)
+level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(NTHREADS) level_split_kernel(const LevelArgs p
 
     // work split: the workgroups that share an XCD (blockIdx % 8) walk one contiguous slice
     // of the item list together
-    const int n_items = p.n_rows * p.n_chunks;
+    const int n_items = p.n_groups * p.n_chunks;
     const int wpx = gridDim.x >> 3;                       // grid is a multiple of 8
     const int xcd = blockIdx.x & 7;
     const int q = n_items >> 3, rem = n_items & 7;
@@ -238,129 +249,148 @@ __global__ void __launch_bounds__(NTHREADS) level_split_kernel(const LevelArgs p
     const int len = q + (xcd < rem ? 1 : 0);
     int t = blockIdx.x >> 3;
     if (t >= len) return;
-    unsigned tl = threadIdx.x;                            // re-materialised per item (see asm below)
+    unsigned tl = threadIdx.x;                            // re-materialised per stage (see asm below)
 
     // Staging registers: STG float4 per thread cover a whole source row.  Loads and LDS
     // writes are UNCONDITIONAL: level matrices and the LDS buffer are padded so that the
     // over-read / over-write past the row's end is harmless (a per-element guard makes hipcc
     // keep the array in scratch and wait on every load).
     f4_t pre[STG];
-#define load_pre(SRC)                                                                            \
-    do {                                                                                         \
-        const float *src_ = (SRC);                                                               \
-        _Pragma("unroll") for (int k_ = 0; k_ < STG; ++k_)                                       \
-            pre[k_] = ld_off<f4_t>(src_, (tl + k_ * NT) * 16u);                                  \
-    } while (0)
-#define store_pre()                                                                              \
-    do {                                                                                         \
-        _Pragma("unroll") for (int k_ = 0; k_ < STG; ++k_)                                       \
-            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_]; \
-    } while (0)
-    // row A of item `it` (wave-uniform => scalar registers)
-    auto row_a_of = [&](int it) -> const float * {
-        const int w = it / p.n_chunks;
-        const int i = __builtin_amdgcn_readfirstlane(p.rows[w]);
-        const int Ai = __builtin_amdgcn_readfirstlane(p.srcA[i]);
-        return p.psi + (long long)Ai * p.ld_prev;
-    };
+    unsigned pk[CPT];                                     // A_j | B_j << 16 of this thread's columns
+    float pa[CPT], pb[CPT];                               // A-row terms of this thread's columns
 
-    load_pre(row_a_of(begin + t));
+    // ---- stage state (all wave-uniform) ----
+    int it = begin + t;                                   // current item
+    int g = it / p.n_chunks;
+    int chunk = it - g * p.n_chunks;
+    int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
+    int w = wb;                                           // child whose B row is the current stage (B stages)
+    bool stage_is_a = true;
+    bool have_next = t + wpx < len;
+    unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
+
+#pragma unroll
+    for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
+
     for (;;) {
-        const bool have_next = t + wpx < len;
-        // ---- this item's context, all wave-uniform ----
-        const int it = begin + t;
-        const int w = it / p.n_chunks;
-        const int chunk = it - w * p.n_chunks;
-        const int ri = __builtin_amdgcn_readfirstlane(p.rows[w]);
-        const int orow = p.out_rows ? __builtin_amdgcn_readfirstlane(p.out_rows[w]) : ri;
-        const int Ai = __builtin_amdgcn_readfirstlane(p.srcA[ri]);
-        const int Bi = __builtin_amdgcn_readfirstlane(p.srcB[ri]);
-        const int oi = __builtin_amdgcn_readfirstlane(p.ord[ri]);
-        const bool new_i = oi < 0;
-        const int ord_i = oi & kOrdMask;
-        const bool hasB = Bi != p.n_prev;
-        const float *rowA = p.psi + (long long)Ai * p.ld_prev;
-        const float *rowB = p.psi + (long long)Bi * p.ld_prev;
-        float *orowp = p.out + (long long)orow * p.ld;
-        const int e_ij = (new_i ? -1 : 0) - 1;           // weight 2^e: row weight times the column's 1/2
-        // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
-        float diag = 0.f;
-        if (new_i) diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(rowA[Bi]));
-        // the next item's row A (prefetched during this item's last stage); resolved here,
-        // where the wave is about to wait for its own staging loads anyway
-        const float *nextA = have_next ? row_a_of(it + wpx) : rowA;
-
-        const unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-        const unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
-        // keep the per-column address arithmetic inside the loop: hoisted out it costs two
-        // VGPRs per column and spills
+        // keep the per-column address arithmetic inside the loop: hoisted out it costs VGPRs
+        // per column.  z0 is a zero the compiler cannot see through: XOR-ing the loop-carried
+        // arrays with it stops hipcc from hoisting their Float64 conversions / LDS addresses.
+        unsigned z0 = 0;
+        asm volatile("" : "+s"(z0));
         asm volatile("" : "+v"(tl));
         __builtin_assume(tl < NT);
+
         __syncthreads();                                // previous gathers are done with the buffer
-        store_pre();
+#pragma unroll
+        for (int k_ = 0; k_ < STG; ++k_)
+            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
         __syncthreads();
-        // index words first (older than the prefetch => the gathers need not wait for it);
-        // the index arrays are padded, so no clamp
-        unsigned pk[CPT];
+
+        // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
+        //      order, so the gathers below only wait for these) and the next stage's source ----
+        int4 dsc = make_int4(0, 0, 0, 0);
         unsigned long long hi_bits = 0;                 // generic layout only: row climbs first
+        int oj[POS_ORD ? 1 : CPT];
+        int nextB;                                      // B source of the next child, or n_prev
+        if (stage_is_a) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) pk[k] = ld_off<unsigned>(p.pk, (cb + tl + k * NT) * 4u);
-        if (!POS_ORD) {
-            int oj[CPT];
-#pragma unroll
-            for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
-            if (hasB) load_pre(rowB);
-            else if (have_next) load_pre(nextA);
-#pragma unroll
-            for (int k = 0; k < CPT; ++k)
-                hi_bits |= (unsigned long long)(ord_i > (oj[k] & kOrdMask) ? 1u : 0u) << k;
+            for (int k = 0; k < CPT; ++k) pk[k] = ld_off<unsigned>(p.pk, (cb + tl + k * NT) * 4u);
+            nextB = desc[wb].z;
         } else {
-            if (hasB) load_pre(rowB);
-            else if (have_next) load_pre(nextA);
-        }
-        float pa[CPT], pb[CPT];
+            dsc = desc[w];
+            if (!POS_ORD) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { pa[k] = sR[pk[k] & 0xffff]; pb[k] = sR[pk[k] >> 16]; }
-        if (!hasB) {
+                for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
+            }
+            nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
+        }
+        // next stage: B row of the next child that has one, else row A of the next item
+        // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
+        const int next_item = it + wpx;
+        const int gn = have_next ? next_item / p.n_chunks : g;
+        const int nextAi = grp[gn].y;
+        {
+            const float *src = p.psi + (long long)(nextB != p.n_prev ? nextB : nextAi) * p.ld_prev;
+#pragma unroll
+            for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+        }
+
+        // ---- part 2: gathers from the staged row ----
+        int wfin_b, wfin_e;                             // children without a B source to finish now
+        if (stage_is_a) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { pa[k] = sR[pk[k] & 0xffff]; pb[k] = sR[pk[k] >> 16]; }
+            wfin_b = wb;                                // if the first child has no B, none has
+            wfin_e = (nextB == p.n_prev) ? we : wb;
+        } else {
+            const int ri = dsc.x, orow = dsc.y, oi = dsc.w;
+            const bool new_i = oi < 0;
+            const int ord_i = oi & kOrdMask;
+            float *orowp = p.out + (long long)orow * p.ld;
+            const int e_ij = (new_i ? -1 : 0) - 1;       // 2^e: row weight times the column's 1/2
+            // diagonal of a new member: 1/2 + Psi[A][B]/2 = 1/2 + Psi[B][A]/2 (bit-symmetric)
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
+            if (!POS_ORD) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k)
+                    hi_bits |= (unsigned long long)(ord_i > (oj[POS_ORD ? 0 : k] & kOrdMask) ? 1u : 0u) << k;
+            }
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const unsigned j = cb + tl + k * NT;
+                const unsigned pkk = pk[k] ^ z0;
+                const float c = sR[pkk & 0xffff], d = sR[pkk >> 16];
                 if (j < ce) {
-                    const float v = combine_e(pa[k], pb[k], 0.f, 0.f, true, e_ij);
+                    const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
+                    const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z0),
+                                              __uint_as_float(__float_as_uint(pb[k]) ^ z0), c, d, i_hi, e_ij);
                     st_off<float>(orowp, j * 4u, (j == (unsigned)ri && new_i) ? diag : v);
                 }
             }
-        } else {
-            __syncthreads();
-            store_pre();                                // row B (waits for its loads here)
-            __syncthreads();
-            if (have_next) load_pre(nextA);
-            // forget the LDS / store addresses derived in pass 1 (kept live across the barrier
-            // they cost several VGPRs per column): re-derive them from pk and tl
-#pragma unroll
-            for (int k = 0; k < CPT; ++k) asm volatile("" : "+v"(pk[k]));
-            unsigned tl2 = tl;
-            asm volatile("" : "+v"(tl2));
-            __builtin_assume(tl2 < NT);
+            wfin_b = w + 1;
+            wfin_e = (nextB == p.n_prev) ? we : w + 1;
+        }
+        // children without a B source (dragged or one-parent rows): finish from the A-row terms
+        for (int wf = wfin_b; wf < wfin_e; ++wf) {
+            unsigned z1 = 0, tlf = tl;                  // opaque again: nothing per-column may be hoisted
+            asm volatile("" : "+s"(z1));
+            asm volatile("" : "+v"(tlf));
+            __builtin_assume(tlf < NT);
+            const int4 df = desc[wf];
+            const bool new_f = df.w < 0;
+            float *orowp = p.out + (long long)df.y * p.ld;
+            const int e_ij = (new_f ? -1 : 0) - 1;
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                const unsigned j = cb + tl2 + k * NT;
-                const float c = sR[pk[k] & 0xffff], d = sR[pk[k] >> 16];
+                const unsigned j = cb + tlf + k * NT;
                 if (j < ce) {
-                    const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
-                    const float v = combine_e(pa[k], pb[k], c, d, i_hi, e_ij);
-                    st_off<float>(orowp, j * 4u, (j == (unsigned)ri && new_i) ? diag : v);
+                    const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z1),
+                                              __uint_as_float(__float_as_uint(pb[k]) ^ z1), 0.f, 0.f, true, e_ij);
+                    st_off<float>(orowp, j * 4u, (j == (unsigned)df.x && new_f) ? 0.5f : v);
                 }
             }
         }
-        // zero columns [n, ld): the "none" column of this level and its pitch padding
-        if (chunk == p.n_chunks - 1)
-            for (unsigned j = p.n + tl; j < (unsigned)p.ld; j += NT) orowp[j] = 0.f;
-        if (!have_next) break;
-        t += wpx;
+
+        // ---- advance the stage state ----
+        if (nextB != p.n_prev) {                        // next stage: B row of the next child
+            w = stage_is_a ? wb : w + 1;
+            stage_is_a = false;
+        } else {                                        // next stage: row A of the next item
+            if (!have_next) break;
+            t += wpx;
+            it = next_item;
+            g = gn;
+            chunk = it - g * p.n_chunks;
+            wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
+            w = wb;
+            stage_is_a = true;
+            have_next = t + wpx < len;
+            cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
+        }
     }
-#undef load_pre
-#undef store_pre
 }
 
 // ---- HALF: fallback for cuts too wide for one row in LDS (> ~40k members) --------------------
@@ -440,6 +470,15 @@ __global__ void half_identity_kernel(float *m, long long ld, int n, const int *o
     if (r < n) m[orow * ld + r] = 0.5f;
 }
 
+// zero columns [n, ld) of n_rows rows (the "none" column of a level and its pitch padding)
+__global__ void zero_cols_kernel(float *out, long long ld, int n, int n_rows)
+{
+    const int w = static_cast<int>(ld) - n;                       // <= 64 columns
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = idx / w;
+    if (r < n_rows) out[r * ld + n + (idx - r * w)] = 0.f;
+}
+
 // out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
 __global__ void colperm_kernel(const float *in, float *out, long long ld, int n, const int *perm)
 {
@@ -475,7 +514,32 @@ struct DeviceStep {
     int *srcA = nullptr, *srcB = nullptr, *ord = nullptr, *work = nullptr, *b_rel = nullptr;
     unsigned *pk = nullptr;
     Segment *segs = nullptr;
+    int4 *desc = nullptr;      // SPLIT: per work row (storage row, output row, B source, ord word)
+    int2 *grp = nullptr;       // SPLIT: per sibling group (first work row, A source) + terminator
+    int n_groups = 0;
 };
+
+// Sibling groups of a work list (rows sorted by (A source, B source); "no B" = n_prev sorts last):
+// runs of equal A source.  out_rows == nullptr => output row = storage row.
+static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows,
+                         std::vector<int4> &desc, std::vector<int2> &grp)
+{
+    desc.resize(n_rows);
+    grp.clear();
+    int lastA = -1;
+    // groups are capped: a workgroup walks a group's children one after the other, so one huge
+    // group (e.g. all parentless rows share "no A source") would be a serial tail
+    static const int max_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 16;
+    for (int w = 0; w < n_rows; ++w) {
+        const int i = rows[w];
+        desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);
+        if (w == 0 || s.srcA[i] != lastA || w - grp.back().x >= max_group) {
+            grp.push_back(make_int2(w, s.srcA[i]));
+            lastA = s.srcA[i];
+        }
+    }
+    grp.push_back(make_int2(n_rows, 0));
+}
 
 struct genphi_plan {
     Plan plan;
@@ -489,6 +553,9 @@ struct genphi_plan {
     std::vector<DeviceStep> dsteps;
     int *d_final_perm = nullptr;
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
+    int4 *d_shard_desc = nullptr;
+    int2 *d_shard_grp = nullptr;
+    int shard_groups = 0;
     int64_t shard_cap = 0, shard_r0 = -1, shard_r1 = -1;
     float *buf[2] = {nullptr, nullptr};
     size_t buf_floats[2] = {0, 0};
@@ -508,6 +575,8 @@ static void free_device(genphi_plan *p)
     (void)hipFree(p->idx_blob);
     (void)hipFree(p->d_shard_rows);
     (void)hipFree(p->d_shard_out_rows);
+    (void)hipFree(p->d_shard_desc);
+    (void)hipFree(p->d_shard_grp);
     (void)hipFree(p->buf[0]);
     (void)hipFree(p->buf[1]);
     (void)hipFree(p->result);
@@ -599,7 +668,7 @@ static int upload_plan(genphi_plan *p, int device)
     size_t total = 256;
     for (const LevelStep &s : pl.steps) {
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int)) + al(s.b_rel.size() * sizeof(int)) +
-                 al(s.segs.size() * sizeof(Segment));
+                 al(s.segs.size() * sizeof(Segment)) + al(s.n * sizeof(int4)) + al((s.n + 1) * sizeof(int2));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
@@ -627,6 +696,14 @@ static int upload_plan(genphi_plan *p, int device)
         }
         d.b_rel = reinterpret_cast<int *>(put(s.b_rel.data(), s.b_rel.size() * sizeof(int)));
         d.segs = reinterpret_cast<Segment *>(put(s.segs.data(), s.segs.size() * sizeof(Segment)));
+        if (s.mode == genphi::kModeSplit) {
+            std::vector<int4> desc;
+            std::vector<int2> grp;
+            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.n), desc, grp);
+            d.n_groups = static_cast<int>(grp.size()) - 1;
+            d.desc = reinterpret_cast<int4 *>(put(desc.data(), desc.size() * sizeof(int4)));
+            d.grp = reinterpret_cast<int2 *>(put(grp.data(), grp.size() * sizeof(int2)));
+        }
     }
     p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
     HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
@@ -681,7 +758,7 @@ static int block_size_for(int64_t n)
 }
 
 static int launch_level(genphi_plan *p, int step, const float *psi, float *out, const int *rows,
-                        const int *out_rows, int n_rows, int kernel)
+                        const int *out_rows, int n_rows, int kernel, const int4 *desc, const int2 *grp, int n_groups)
 {
     const LevelStep &s = p->plan.steps[step];
     const DeviceStep &d = p->dsteps[step];
@@ -721,12 +798,13 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
         a.chunk_cols = cpt * nt;
         a.n_chunks = n_chunks;
-        const long long n_items = static_cast<long long>(n_rows) * n_chunks;
+        a.n_groups = n_groups;
+        const long long n_items = static_cast<long long>(n_groups) * n_chunks;
         const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
 #define GENPHI_LAUNCH_SPLIT2(C, S, O)                                                                \
         do {                                                                                         \
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_split_kernel<nt, C, S, O>), lds)); \
-            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a); \
+            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a, desc, grp); \
         } while (0)
 #define GENPHI_LAUNCH_SPLIT1(C, O)                                                                   \
         do {                                                                                         \
@@ -745,6 +823,14 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         }
 #undef GENPHI_LAUNCH_SPLIT2
 #undef GENPHI_LAUNCH_SPLIT1
+        // zero columns [n, ld) of the rows just written (the "none" column and the pitch padding);
+        // kept out of the kernel, where it cost registers inside the per-child loop
+        if (s.ld > s.n) {
+            const int64_t out_rows_n = out_rows ? n_rows : s.n;
+            const long long cells = static_cast<long long>(out_rows_n) * (s.ld - s.n);
+            hipLaunchKernelGGL(zero_cols_kernel, dim3(static_cast<unsigned>((cells + 255) / 256)), dim3(256), 0, p->stream,
+                               out, static_cast<long long>(s.ld), static_cast<int>(s.n), static_cast<int>(out_rows_n));
+        }
     } else {
         int wmax = 0;
         for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
@@ -800,9 +886,14 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
     // shard row lists for the last step: storage row of proband r, output row r - r0
     if (n_rows > p->shard_cap) {
-        if (p->d_shard_rows) { HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows)); }
+        if (p->d_shard_rows) {
+            HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows));
+            HIP_TRY(hipFree(p->d_shard_desc)); HIP_TRY(hipFree(p->d_shard_grp));
+        }
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_rows), n_rows * sizeof(int)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_desc), n_rows * sizeof(int4)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_grp), (n_rows + 1) * sizeof(int2)));
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
@@ -823,6 +914,14 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         for (int64_t k = 0; k < n_rows; ++k) { rows[k] = key[k].first; orows[k] = key[k].second; }
         HIP_TRY(hipMemcpyAsync(p->d_shard_rows, rows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(p->d_shard_out_rows, orows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
+        std::vector<int4> desc;
+        std::vector<int2> grp;
+        if (n_steps > 0 && pl.steps[n_steps - 1].mode == genphi::kModeSplit) {
+            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), desc, grp);
+            p->shard_groups = static_cast<int>(grp.size()) - 1;
+            HIP_TRY(hipMemcpyAsync(p->d_shard_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->d_shard_grp, grp.data(), grp.size() * sizeof(int2), hipMemcpyHostToDevice, p->stream));
+        }
         HIP_TRY(hipStreamSynchronize(p->stream));      // host vectors go out of scope
         p->shard_r0 = r0; p->shard_r1 = r1;
     }
@@ -849,13 +948,15 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             const bool last = s == n_steps - 1;
             if (!last) {
                 float *out = p->buf[(s + 1) & 1];
-                rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel);
+                rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
+                                  p->dsteps[s].desc, p->dsteps[s].grp, p->dsteps[s].n_groups);
                 if (rc) return rc;
                 // the all-zero "none" row of this level
                 HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
             } else {
                 float *out = need_perm ? p->final_tmp : p->result;
-                rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel);
+                rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel,
+                                  p->d_shard_desc, p->d_shard_grp, p->shard_groups);
                 if (rc) return rc;
                 if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
                 if (need_perm) {
