@@ -96,6 +96,45 @@ def cpu_baseline(ped, pro, sizes, budget_s=20.0):
                       f"extrapolated by evaluation count"}
 
 
+def shard_rows(n, rank, world):
+    """Final-level row shard [r0, r1) of `rank`: contiguous, disjoint, covering [0, n)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal (gloo) of everything around the compute call for N > 1: the plan, the row
+    shards, the barrier and the max-over-ranks reduction.  Prints one JSON line on rank 0."""
+    import torch
+    import torch.distributed as dist
+    import genlib_jl_amd as gen
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    ped, pro, desc = load_workload(args.workload)
+    pl = gen.plan(ped, pro)
+    n = pl.n_probands
+    r0, r1 = shard_rows(n, rank, world)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0 + 1e-3 * (rank + 1)          # distinct per rank: the MAX must win
+    shards = [None] * world
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall_max = float(tt.item())
+        dist.all_gather_object(shards, (r0, r1))
+    else:
+        wall_max, shards = wall, [(r0, r1)]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "n_probands": n, "shards": shards,
+                          "wall_is_max": wall_max >= wall, "levels": len(pl.levels()[0])}), flush=True)
+    pl.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +143,12 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N > 1 plumbing: plan + shard + barrier + max-reduce, no compute")
     args = ap.parse_args()
 
     import torch
@@ -113,14 +158,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the gen.phi product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import genlib_jl_amd as gen
     ped, pro, desc = load_workload(args.workload)
@@ -128,7 +180,7 @@ def main():
     sizes, both = pl.levels()
     n = pl.n_probands
     # final-level row shard of this rank (proband tiles across the GPUs; no collective)
-    r0, r1 = (n * rank) // world, (n * (rank + 1)) // world
+    r0, r1 = shard_rows(n, rank, world)
     rows = (r0, r1) if world > 1 else None
 
     def barrier():
@@ -150,7 +202,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
@@ -189,7 +241,7 @@ def main():
                        "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
                        "level_ms": [round(float(x), 4) for x in lvl] if len(lvl) <= 64 else None,
                        "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
-            "roofline": {"bound": "hbm", "kernel": "level_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "level_split_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),

@@ -529,7 +529,7 @@ static void build_groups(const LevelStep &s, const int *rows, const int *out_row
     int lastA = -1;
     // groups are capped: a workgroup walks a group's children one after the other, so one huge
     // group (e.g. all parentless rows share "no A source") would be a serial tail
-    static const int max_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 16;
+    static const int max_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 4;
     for (int w = 0; w < n_rows; ++w) {
         const int i = rows[w];
         desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);

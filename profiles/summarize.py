@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Summarise a profiles/collect.sh run (gpurun_out/prof_<tag>_<workload>/) into the tracked files
+    profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+    profiles/<tag>_<workload>_levels.csv         per level-kernel dispatch: ms, HBM read/write bytes, L2 hit %
+    profiles/traffic_<workload>.json             what bench.py reports as roofline.traffic
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB and
+collected in separate passes; on gfx950 FETCH_SIZE reports exactly half of a wide (16 B/lane)
+coalesced read stream -- the staging loads of the level kernels are that -- so it is doubled;
+WRITE_SIZE is taken as is (it matches the known output bytes of these kernels to <1 %)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, wl = (sys.argv + ["r01", "cfg4"])[1:3]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
+dst = os.path.join(root, "profiles")
+
+
+def one(pattern):
+    return glob.glob(os.path.join(src, pattern))[0]
+
+
+shutil.copy(one("kt/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
+
+
+def agg(path):
+    d = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        k = int(r["Dispatch_Id"])
+        e = d.setdefault(k, {"name": r["Kernel_Name"], "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
+        e[r["Counter_Name"]] = float(r["Counter_Value"])
+    return d
+
+
+F, W = agg(one("pmc_fetch/*/*counter_collection.csv")), agg(one("pmc_write/*/*counter_collection.csv"))
+rows, tot = [], 0.0
+for k in F:
+    if "level_" not in F[k]["name"] or k not in W:
+        continue
+    rd = F[k].get("FETCH_SIZE", 0.0) * 1024 * 2            # KiB -> B, gfx950 wide-read correction
+    wr = W[k].get("WRITE_SIZE", 0.0) * 1024
+    hit, miss = W[k].get("TCC_HIT_sum", 0.0), W[k].get("TCC_MISS_sum", 0.0)
+    short = F[k]["name"].split("::")[-1].split("(")[0]
+    rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1)))
+    tot += rd + wr
+with open(os.path.join(dst, f"{tag}_{wl}_levels.csv"), "w") as fh:
+    fh.write("dispatch,kernel,ms_under_pmc,hbm_read_bytes,hbm_write_bytes,l2_hit_pct\n")
+    for r in rows:
+        fh.write(",".join(str(x) for x in r) + "\n")
+n = max(len(rows), 1)
+json.dump({"workload": wl, "tag": tag, "level_kernel_launches_profiled": len(rows),
+           "hbm_bytes_per_launch": tot / n,
+           "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE in separate passes, "
+                     "KiB -> bytes, averaged over the level-kernel launches of 2 bench steps"},
+          open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
+print(f"{len(rows)} launches, {tot / n / 1e9:.3f} GB per launch")
