@@ -45,7 +45,7 @@ for k in F:
     rd = F[k].get("FETCH_SIZE", 0.0) * 1024 * 2            # KiB -> B, gfx950 wide-read correction
     wr = W[k].get("WRITE_SIZE", 0.0) * 1024
     hit, miss = W[k].get("TCC_HIT_sum", 0.0), W[k].get("TCC_MISS_sum", 0.0)
-    short = F[k]["name"].split("::")[-1].split("(")[0]
+    short = F[k]["name"].split("(anonymous namespace)::")[1].split("(")[0]
     rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1)))
     tot += rd + wr
 with open(os.path.join(dst, f"{tag}_{wl}_levels.csv"), "w") as fh:
