@@ -258,6 +258,11 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     f4_t pre[STG];
     unsigned pk[CPT];                                     // A_j | B_j << 16 of this thread's columns
     float pa[CPT], pb[CPT];                               // A-row terms of this thread's columns
+    // generic layout: per child of the group (<= kMaxGroupGeneric), bit k = "the row member
+    // has the larger rank than column k".  Built once per item in stage A, where the rank
+    // words oj[] die before pa/pb are born: costs 4 VGPRs instead of CPT.
+    unsigned hb0 = 0, hb1 = 0, hb2 = 0, hb3 = 0;
+    static_assert(CPT <= 32, "one 32-bit mask per child");
 
     // ---- stage state (all wave-uniform) ----
     int it = begin + t;                                   // current item
@@ -291,19 +296,34 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
         //      order, so the gathers below only wait for these) and the next stage's source ----
         int4 dsc = make_int4(0, 0, 0, 0);
-        unsigned long long hi_bits = 0;                 // generic layout only: row climbs first
-        int oj[POS_ORD ? 1 : CPT];
         int nextB;                                      // B source of the next child, or n_prev
         if (stage_is_a) {
+            if (!POS_ORD) {
+                // rank words first, alone: they are folded into the per-child masks and dead
+                // before pk / the prefetch are even issued (one exposed L2 round trip per item)
+                int oj[CPT];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
+                const int o0 = desc[wb].w & kOrdMask;
+                const int o1 = desc[min(wb + 1, we - 1)].w & kOrdMask;
+                const int o2 = desc[min(wb + 2, we - 1)].w & kOrdMask;
+                const int o3 = desc[min(wb + 3, we - 1)].w & kOrdMask;
+                hb0 = hb1 = hb2 = hb3 = 0;
+#pragma unroll
+                for (int k = CPT - 1; k >= 0; --k) {    // shift-accumulate: bit k ends up at position k
+                    const int ok = oj[k] & kOrdMask;
+                    hb0 = (hb0 << 1) | (o0 > ok ? 1u : 0u);
+                    hb1 = (hb1 << 1) | (o1 > ok ? 1u : 0u);
+                    hb2 = (hb2 << 1) | (o2 > ok ? 1u : 0u);
+                    hb3 = (hb3 << 1) | (o3 > ok ? 1u : 0u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int k = 0; k < CPT; ++k) pk[k] = ld_off<unsigned>(p.pk, (cb + tl + k * NT) * 4u);
             nextB = desc[wb].z;
         } else {
             dsc = desc[w];
-            if (!POS_ORD) {
-#pragma unroll
-                for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
-            }
             nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
         }
         // next stage: B row of the next child that has one, else row A of the next item
@@ -327,16 +347,12 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         } else {
             const int ri = dsc.x, orow = dsc.y, oi = dsc.w;
             const bool new_i = oi < 0;
-            const int ord_i = oi & kOrdMask;
             float *orowp = p.out + (long long)orow * p.ld;
             const int e_ij = (new_i ? -1 : 0) - 1;       // 2^e: row weight times the column's 1/2
             // diagonal of a new member: 1/2 + Psi[A][B]/2 = 1/2 + Psi[B][A]/2 (bit-symmetric)
             const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
-            if (!POS_ORD) {
-#pragma unroll
-                for (int k = 0; k < CPT; ++k)
-                    hi_bits |= (unsigned long long)(ord_i > (oj[POS_ORD ? 0 : k] & kOrdMask) ? 1u : 0u) << k;
-            }
+            const int qk = w - wb;                      // which child of the group (wave-uniform)
+            const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const unsigned j = cb + tl + k * NT;
@@ -529,7 +545,9 @@ static void build_groups(const LevelStep &s, const int *rows, const int *out_row
     int lastA = -1;
     // groups are capped: a workgroup walks a group's children one after the other, so one huge
     // group (e.g. all parentless rows share "no A source") would be a serial tail
-    static const int max_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 4;
+    static const int env_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 4;
+    // the generic (rank-word) kernel variant keeps one bitmask per child: at most 4 children
+    const int max_group = s.pos_ord ? env_group : std::min(env_group, 4);
     for (int w = 0; w < n_rows; ++w) {
         const int i = rows[w];
         desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);
@@ -793,7 +811,8 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         // LDS must also absorb the unconditional over-write past the row's end
         const size_t lds = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
         const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
-        const int max_cpt = (s.pos_ord && stg_inst <= 8) ? 26 : 16;  // register budget of the instantiations
+        // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
+        const int max_cpt = stg_inst <= 8 ? (s.pos_ord ? 26 : 25) : 16;
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
         a.chunk_cols = cpt * nt;
@@ -819,7 +838,9 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
             else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(26, 6, true); else GENPHI_LAUNCH_SPLIT2(26, 8, true); }
         } else {
             if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, false);
-            else GENPHI_LAUNCH_SPLIT1(16, false);
+            else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, false);
+            else if (cpt <= 24) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, false); else GENPHI_LAUNCH_SPLIT2(24, 8, false); }
+            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(25, 6, false); else GENPHI_LAUNCH_SPLIT2(25, 8, false); }
         }
 #undef GENPHI_LAUNCH_SPLIT2
 #undef GENPHI_LAUNCH_SPLIT1
