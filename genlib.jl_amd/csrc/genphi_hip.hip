@@ -97,6 +97,7 @@ struct LevelArgs {
     int chunk_cols;          // SPLIT: columns per chunk (multiple of blockDim)
     int n_chunks;            // SPLIT: column chunks per row (work item = sibling group x chunk)
     int n_groups;            // SPLIT: sibling groups (runs of equal A source in the work list)
+    int slot_off;            // SPLIT: float offset in LDS of the two work-queue hand-over slots
 };
 
 // ---- shared pieces of the row kernels --------------------------------------------------------
@@ -233,22 +234,32 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // pipeline (scratch reloads wait on vmcnt(0), i.e. on the prefetch in flight).
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp)
+level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
     float *sR = lds;
 
-    // work split: the workgroups that share an XCD (blockIdx % 8) walk one contiguous slice
-    // of the item list together
+    // Work split: the workgroups that share an XCD (blockIdx % 8) drain one contiguous slice of
+    // the item list together, in order, through a per-slice atomic counter (queue[xcd], zeroed
+    // by the host): items cost 1..5 stages, a static split leaves a tail.  Thread 0 draws the
+    // item after next during stage A of each item and hands it over through an LDS slot, so
+    // the draw's latency never sits in front of a prefetch.
     const int n_items = p.n_groups * p.n_chunks;
-    const int wpx = gridDim.x >> 3;                       // grid is a multiple of 8
     const int xcd = blockIdx.x & 7;
     const int q = n_items >> 3, rem = n_items & 7;
     const int begin = xcd * q + min(xcd, rem);
     const int len = q + (xcd < rem ? 1 : 0);
-    int t = blockIdx.x >> 3;
-    if (t >= len) return;
+    int *slot = reinterpret_cast<int *>(lds + p.slot_off);
+    if (threadIdx.x == 0) {
+        slot[0] = atomicAdd(&queue[xcd], 1);
+        slot[1] = atomicAdd(&queue[xcd], 1);
+    }
+    __syncthreads();
+    int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);  // this item / the next one (slice-local)
+    int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
+    if (cur_l >= len) return;
+    int kc = 0;                                           // items this workgroup has started
     unsigned tl = threadIdx.x;                            // re-materialised per stage (see asm below)
 
     // Staging registers: STG float4 per thread cover a whole source row.  Loads and LDS
@@ -265,13 +276,13 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     static_assert(CPT <= 32, "one 32-bit mask per child");
 
     // ---- stage state (all wave-uniform) ----
-    int it = begin + t;                                   // current item
+    int it = begin + cur_l;                               // current item
     int g = it / p.n_chunks;
     int chunk = it - g * p.n_chunks;
     int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
     int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
-    bool have_next = t + wpx < len;
+    bool have_next = nxt_l < len;
     unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
     unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
 
@@ -298,6 +309,14 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         int4 dsc = make_int4(0, 0, 0, 0);
         int nextB;                                      // B source of the next child, or n_prev
         if (stage_is_a) {
+            // the item after next: drawn now by thread 0 (oldest memory op of the stage, so
+            // waiting for it never waits for the prefetch), read by everyone one item later
+            if (kc > 0) {
+                nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
+                have_next = nxt_l < len;
+            }
+            if (threadIdx.x == 0) slot[kc & 1] = atomicAdd(&queue[xcd], 1);
+            ++kc;
             if (!POS_ORD) {
                 // rank words first, alone: they are folded into the per-child masks and dead
                 // before pk / the prefetch are even issued (one exposed L2 round trip per item)
@@ -328,7 +347,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         }
         // next stage: B row of the next child that has one, else row A of the next item
         // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
-        const int next_item = it + wpx;
+        const int next_item = begin + nxt_l;
         const int gn = have_next ? next_item / p.n_chunks : g;
         const int nextAi = grp[gn].y;
         {
@@ -395,14 +414,12 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             stage_is_a = false;
         } else {                                        // next stage: row A of the next item
             if (!have_next) break;
-            t += wpx;
             it = next_item;
             g = gn;
             chunk = it - g * p.n_chunks;
             wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
             w = wb;
             stage_is_a = true;
-            have_next = t + wpx < len;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
             ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
         }
@@ -545,7 +562,7 @@ static void build_groups(const LevelStep &s, const int *rows, const int *out_row
     int lastA = -1;
     // groups are capped: a workgroup walks a group's children one after the other, so one huge
     // group (e.g. all parentless rows share "no A source") would be a serial tail
-    static const int env_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 4;
+    static const int env_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 8;
     // the generic (rank-word) kernel variant keeps one bitmask per child: at most 4 children
     const int max_group = s.pos_ord ? env_group : std::min(env_group, 4);
     for (int w = 0; w < n_rows; ++w) {
@@ -571,6 +588,7 @@ struct genphi_plan {
     std::vector<DeviceStep> dsteps;
     int *d_final_perm = nullptr;
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
+    int *d_queues = nullptr;        // 8 work-queue counters per level step
     int4 *d_shard_desc = nullptr;
     int2 *d_shard_grp = nullptr;
     int shard_groups = 0;
@@ -594,6 +612,7 @@ static void free_device(genphi_plan *p)
     (void)hipFree(p->d_shard_rows);
     (void)hipFree(p->d_shard_out_rows);
     (void)hipFree(p->d_shard_desc);
+    (void)hipFree(p->d_queues);
     (void)hipFree(p->d_shard_grp);
     (void)hipFree(p->buf[0]);
     (void)hipFree(p->buf[1]);
@@ -727,6 +746,7 @@ static int upload_plan(genphi_plan *p, int device)
     HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
 
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_queues), (pl.steps.size() + 1) * 8 * sizeof(int)));
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
     for (int c = 0; c + 1 < pl.n_levels; ++c)
@@ -807,9 +827,11 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         a.lds_row = lds_row;
         constexpr int nt = 1024;
         const int stg = (lds_row / 4 + nt - 1) / nt;                 // float4 per thread per staged row
-        const int stg_inst = stg <= 6 ? 6 : (stg <= 8 ? 8 : 10);
+        const int stg_inst = stg <= 6 ? 6 : (stg <= 8 ? 8 : 9);    // planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
         // LDS must also absorb the unconditional over-write past the row's end
-        const size_t lds = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
+        const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
+        const size_t lds = lds_stage + 16;
+        a.slot_off = static_cast<int>(lds_stage / sizeof(float));
         const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
         const int max_cpt = stg_inst <= 8 ? (s.pos_ord ? 26 : 25) : 16;
@@ -820,16 +842,17 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         a.n_groups = n_groups;
         const long long n_items = static_cast<long long>(n_groups) * n_chunks;
         const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
+        int *queue = p->d_queues + 8 * step;                                  // zeroed at the start of the sweep
 #define GENPHI_LAUNCH_SPLIT2(C, S, O)                                                                \
         do {                                                                                         \
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_split_kernel<nt, C, S, O>), lds)); \
-            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a, desc, grp); \
+            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a, desc, grp, queue); \
         } while (0)
 #define GENPHI_LAUNCH_SPLIT1(C, O)                                                                   \
         do {                                                                                         \
             if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(C, 6, O);                                        \
             else if (stg_inst == 8) GENPHI_LAUNCH_SPLIT2(C, 8, O);                                   \
-            else GENPHI_LAUNCH_SPLIT2(C, 10, O);                                                     \
+            else GENPHI_LAUNCH_SPLIT2(C, 9, O);                                                      \
         } while (0)
         if (s.pos_ord) {
             if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, true);
@@ -948,6 +971,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
 
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_queues, 0, (pl.steps.size() + 1) * 8 * sizeof(int), p->stream));
     if (n_steps == 0) {
         // all probands parentless: result = 1/2 I (src/compute.jl:271-274, loop skipped)
         HIP_TRY(hipMemsetAsync(p->result, 0, static_cast<size_t>(n_rows * ldN) * sizeof(float), p->stream));

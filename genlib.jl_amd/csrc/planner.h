@@ -67,7 +67,7 @@ struct Plan {
 };
 
 struct PlanOptions {
-    int32_t lds_cap_floats = 40448;   // floats of LDS a workgroup may use for staged source rows (2 rows x window)
+    int32_t lds_cap_floats = 36864;   // floats of LDS a workgroup may use for staged source rows (9 * 1024 float4; 160 KB minus the work-queue slots)
 };
 
 // Returns 0 or a GENPHI_ERR_* code (see include/genphi.h); message in err.
