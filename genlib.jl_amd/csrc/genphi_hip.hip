@@ -941,7 +941,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
-        // work order of the shard: rows sharing a source row adjacent (same rule as the planner)
+        // work order of the shard: the planner's reuse order (sibling groups, chained along
+        // shared B sources) restricted to the shard's rows
         std::vector<int> rows(n_rows), orows(n_rows);
         std::vector<std::pair<int, int>> key(n_rows);   // (storage row, out row)
         for (int64_t k = 0; k < n_rows; ++k) {
@@ -950,10 +951,18 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         }
         if (n_steps > 0) {
             const LevelStep &s = pl.steps[n_steps - 1];
-            std::stable_sort(key.begin(), key.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
-                if (s.srcA[a.first] != s.srcA[b.first]) return s.srcA[a.first] < s.srcA[b.first];
-                return s.srcB[a.first] < s.srcB[b.first];
-            });
+            if (s.mode == genphi::kModeHalf) {
+                std::stable_sort(key.begin(), key.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+                    if (s.srcA[a.first] != s.srcA[b.first]) return s.srcA[a.first] < s.srcA[b.first];
+                    return s.srcB[a.first] < s.srcB[b.first];
+                });
+            } else {
+                std::vector<int32_t> ord(n_rows);
+                std::vector<int> out_of(s.n, -1);
+                for (int64_t k = 0; k < n_rows; ++k) { ord[k] = key[k].first; out_of[key[k].first] = key[k].second; }
+                genphi::reuse_order(s, ord);
+                for (int64_t k = 0; k < n_rows; ++k) key[k] = {ord[k], out_of[ord[k]]};
+            }
         }
         for (int64_t k = 0; k < n_rows; ++k) { rows[k] = key[k].first; orows[k] = key[k].second; }
         HIP_TRY(hipMemcpyAsync(p->d_shard_rows, rows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));

@@ -32,6 +32,58 @@ struct Member {
 
 }  // namespace
 
+void reuse_order(const LevelStep &st, std::vector<int32_t> &rows)
+{
+    const int64_t m = static_cast<int64_t>(rows.size());
+    if (m == 0) return;
+    const int32_t none = static_cast<int32_t>(st.n_prev);
+    // rows by (A, B): runs of equal A are the sibling groups ("no B" sorts last inside a group)
+    std::vector<int32_t> byA(rows);
+    std::sort(byA.begin(), byA.end(), [&](int32_t a, int32_t b) {
+        if (st.srcA[a] != st.srcA[b]) return st.srcA[a] < st.srcA[b];
+        if (st.srcB[a] != st.srcB[b]) return st.srcB[a] < st.srcB[b];
+        return a < b;
+    });
+    std::vector<int32_t> byB(rows);
+    std::sort(byB.begin(), byB.end(), [&](int32_t a, int32_t b) {
+        if (st.srcB[a] != st.srcB[b]) return st.srcB[a] < st.srcB[b];
+        return st.srcA[a] < st.srcA[b];
+    });
+    // start offsets of every A value / B value present (values are < n_prev + 1)
+    std::vector<int32_t> a_begin(st.n_prev + 2, -1), a_end(st.n_prev + 2, -1), b_begin(st.n_prev + 2, -1), b_end(st.n_prev + 2, -1);
+    for (int64_t k = 0; k < m; ++k) {
+        const int32_t A = st.srcA[byA[k]], B = st.srcB[byB[k]];
+        if (a_begin[A] < 0) a_begin[A] = static_cast<int32_t>(k);
+        a_end[A] = static_cast<int32_t>(k + 1);
+        if (b_begin[B] < 0) b_begin[B] = static_cast<int32_t>(k);
+        b_end[B] = static_cast<int32_t>(k + 1);
+    }
+    std::vector<char> seen(st.n_prev + 2, 0);
+    std::vector<int32_t> stack, out;
+    out.reserve(m);
+    for (int64_t k0 = 0; k0 < m; ++k0) {
+        const int32_t A0 = st.srcA[byA[k0]];
+        if (seen[A0]) continue;
+        seen[A0] = 1;
+        stack.push_back(A0);
+        while (!stack.empty()) {
+            const int32_t A = stack.back();
+            stack.pop_back();
+            for (int32_t k = a_begin[A]; k < a_end[A]; ++k) {
+                const int32_t r = byA[k];
+                out.push_back(r);
+                const int32_t B = st.srcB[r];
+                if (B == none) continue;
+                for (int32_t t = b_begin[B]; t < b_end[B]; ++t) {      // the other children of this B source
+                    const int32_t A2 = st.srcA[byB[t]];
+                    if (!seen[A2]) { seen[A2] = 1; stack.push_back(A2); }
+                }
+            }
+        }
+    }
+    rows.swap(out);
+}
+
 int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
                int64_t n_pro, const int64_t *pro_ids, const PlanOptions &opt, Plan &plan,
                std::string &err)
@@ -244,13 +296,18 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                 }
             }
             plan.both_counts[c - 1] = dragged;
-            // row processing order: rows with the same A source adjacent in time
+            // row processing order: sibling groups (same A source) adjacent, groups chained
+            // depth-first along shared B sources (see reuse_order)
             st.work.resize(n);
             std::iota(st.work.begin(), st.work.end(), 0);
-            std::stable_sort(st.work.begin(), st.work.end(), [&](int32_t a, int32_t b) {
-                if (st.srcA[a] != st.srcA[b]) return st.srcA[a] < st.srcA[b];
-                return st.srcB[a] < st.srcB[b];
-            });
+            if (in_half) {
+                std::stable_sort(st.work.begin(), st.work.end(), [&](int32_t a, int32_t b) {
+                    if (st.srcA[a] != st.srcA[b]) return st.srcA[a] < st.srcA[b];
+                    return st.srcB[a] < st.srcB[b];
+                });
+            } else {
+                reuse_order(st, st.work);
+            }
             if (in_half) {
                 // column segments: runs of equal (group, bucket); processed bucket-major so a
                 // window is staged once per row

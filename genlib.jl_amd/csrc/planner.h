@@ -75,6 +75,12 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                int64_t n_pro, const int64_t *pro_ids, const PlanOptions &opt, Plan &plan,
                std::string &err);
 
+// Reorders a list of storage rows of cut s+1 for source-row reuse: rows sharing the A source
+// stay adjacent (sibling groups), and groups are visited depth-first along shared B sources, so
+// that the second use of a B (mother) row follows the first closely enough to be served by
+// L2 / the Infinity Cache instead of HBM.
+void reuse_order(const LevelStep &step, std::vector<int32_t> &rows);
+
 inline int64_t pitch_for(int64_t n) { return ((n + 1) + 63) / 64 * 64; }
 
 }  // namespace genphi
