@@ -222,6 +222,25 @@ __device__ __forceinline__ void st_off(void *sbase, unsigned byte_off, T v)
 }
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// Row store of 4 consecutive columns.  AUX = 0: plain store; otherwise a buffer store with that
+// cache-policy word (16 = sc1: write-through, the line is not kept in the XCD's L2, so a
+// streamed output row does not evict the source rows other workgroups are about to stage).
+#ifndef GENPHI_STORE_AUX
+#define GENPHI_STORE_AUX 0
+#endif
+__device__ __forceinline__ void store_row4(float *row, unsigned row_bytes, unsigned byte_off, f4_t v)
+{
+#if GENPHI_STORE_AUX == 0
+    (void)row_bytes;
+    st_off<f4_t>(row, byte_off, v);
+#else
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, byte_off, 0, GENPHI_STORE_AUX);
+#endif
+}
 
 // A work item is (sibling group, column chunk): the rows of a group share source row A, which
 // is staged and gathered ONCE; then only row B is staged per child.  desc[w] = (storage row,
@@ -274,6 +293,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     // words oj[] die before pa/pb are born: costs 4 VGPRs instead of CPT.
     unsigned hb0 = 0, hb1 = 0, hb2 = 0, hb3 = 0;
     static_assert(CPT <= 32, "one 32-bit mask per child");
+    // column of element k of this thread: quads of 4 consecutive columns (16-byte index loads
+    // and row stores), quad q at cb + q * 4 * NT + 4 * tl
+    static_assert(CPT % 4 == 0, "columns are handled in quads");
+    constexpr int NQ = CPT / 4;
 
     // ---- stage state (all wave-uniform) ----
     int it = begin + cur_l;                               // current item
@@ -322,7 +345,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 // before pk / the prefetch are even issued (one exposed L2 round trip per item)
                 int oj[CPT];
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) oj[k] = ld_off<int>(p.ord, (cb + tl + k * NT) * 4u);
+                for (int q = 0; q < NQ; ++q) {
+                    const i4_t v = ld_off<i4_t>(p.ord, (cb + q * 4 * NT + tl * 4) * 4u);
+                    oj[4 * q] = v.x; oj[4 * q + 1] = v.y; oj[4 * q + 2] = v.z; oj[4 * q + 3] = v.w;
+                }
                 const int o0 = desc[wb].w & kOrdMask;
                 const int o1 = desc[min(wb + 1, we - 1)].w & kOrdMask;
                 const int o2 = desc[min(wb + 2, we - 1)].w & kOrdMask;
@@ -339,7 +365,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) pk[k] = ld_off<unsigned>(p.pk, (cb + tl + k * NT) * 4u);
+            for (int q = 0; q < NQ; ++q) {
+                const u4_t v = ld_off<u4_t>(p.pk, (cb + q * 4 * NT + tl * 4) * 4u);
+                pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
+            }
             nextB = desc[wb].z;
         } else {
             dsc = desc[w];
@@ -372,17 +401,24 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
             const int qk = w - wb;                      // which child of the group (wave-uniform)
             const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
+            const unsigned row_bytes = (unsigned)p.ld * 4u;
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const unsigned j = cb + tl + k * NT;
-                const unsigned pkk = pk[k] ^ z0;
-                const float c = sR[pkk & 0xffff], d = sR[pkk >> 16];
-                if (j < ce) {
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned jq = cb + q * 4 * NT + tl * 4;
+                f4_t vq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
+                    const unsigned j = jq + e;
+                    const unsigned pkk = pk[k] ^ z0;
+                    const float c = sR[pkk & 0xffff], d = sR[pkk >> 16];
                     const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
                     const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z0),
                                               __uint_as_float(__float_as_uint(pb[k]) ^ z0), c, d, i_hi, e_ij);
-                    st_off<float>(orowp, j * 4u, (j == (unsigned)ri && new_i) ? diag : v);
+                    vq[e] = (j == (unsigned)ri && new_i) ? diag : v;
                 }
+                // a ragged last quad spills into the padding columns [n, ld), zeroed afterwards
+                if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
             wfin_b = w + 1;
             wfin_e = (nextB == p.n_prev) ? we : w + 1;
@@ -397,14 +433,19 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             const bool new_f = df.w < 0;
             float *orowp = p.out + (long long)df.y * p.ld;
             const int e_ij = (new_f ? -1 : 0) - 1;
+            const unsigned row_bytes = (unsigned)p.ld * 4u;
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const unsigned j = cb + tlf + k * NT;
-                if (j < ce) {
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned jq = cb + q * 4 * NT + tlf * 4;
+                f4_t vq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
                     const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z1),
                                               __uint_as_float(__float_as_uint(pb[k]) ^ z1), 0.f, 0.f, true, e_ij);
-                    st_off<float>(orowp, j * 4u, (j == (unsigned)df.x && new_f) ? 0.5f : v);
+                    vq[e] = (jq + e == (unsigned)df.x && new_f) ? 0.5f : v;
                 }
+                if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
         }
 
@@ -834,10 +875,10 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         a.slot_off = static_cast<int>(lds_stage / sizeof(float));
         const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
-        const int max_cpt = stg_inst <= 8 ? (s.pos_ord ? 26 : 25) : 16;
+        const int max_cpt = stg_inst <= 8 ? 24 : 16;
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
-        a.chunk_cols = cpt * nt;
+        a.chunk_cols = (cpt + 3) / 4 * 4 * nt;                          // whole quads of columns per thread
         a.n_chunks = n_chunks;
         a.n_groups = n_groups;
         const long long n_items = static_cast<long long>(n_groups) * n_chunks;
@@ -857,13 +898,13 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         if (s.pos_ord) {
             if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, true);
             else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, true);
-            else if (cpt <= 24) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, true); else GENPHI_LAUNCH_SPLIT2(24, 8, true); }
-            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(26, 6, true); else GENPHI_LAUNCH_SPLIT2(26, 8, true); }
+            else if (cpt <= 20) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(20, 6, true); else GENPHI_LAUNCH_SPLIT2(20, 8, true); }
+            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, true); else GENPHI_LAUNCH_SPLIT2(24, 8, true); }
         } else {
             if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, false);
             else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, false);
-            else if (cpt <= 24) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, false); else GENPHI_LAUNCH_SPLIT2(24, 8, false); }
-            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(25, 6, false); else GENPHI_LAUNCH_SPLIT2(25, 8, false); }
+            else if (cpt <= 20) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(20, 6, false); else GENPHI_LAUNCH_SPLIT2(20, 8, false); }
+            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, false); else GENPHI_LAUNCH_SPLIT2(24, 8, false); }
         }
 #undef GENPHI_LAUNCH_SPLIT2
 #undef GENPHI_LAUNCH_SPLIT1
