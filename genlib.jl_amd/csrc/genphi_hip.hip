@@ -410,15 +410,19 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 for (int e = 0; e < 4; ++e) {
                     const int k = 4 * q + e;
                     const unsigned j = jq + e;
-                    const unsigned pkk = pk[k] ^ z0;
-                    const float c = sR[pkk & 0xffff], d = sR[pkk >> 16];
+                    const float c = sR[pk[k] & 0xffff], d = sR[pk[k] >> 16];
                     const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
-                    const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z0),
-                                              __uint_as_float(__float_as_uint(pb[k]) ^ z0), c, d, i_hi, e_ij);
-                    vq[e] = (j == (unsigned)ri && new_i) ? diag : v;
+                    vq[e] = combine_e(pa[k], pb[k], c, d, i_hi, e_ij);
                 }
                 // a ragged last quad spills into the padding columns [n, ld), zeroed afterwards
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
+            }
+            // the diagonal entry of a new member is patched by the thread that owns its column
+            // (same thread as the quad store above, so the two stores stay ordered)
+            if (new_i) {
+                const unsigned r = (unsigned)ri - cb;
+                if ((unsigned)ri >= cb && (unsigned)ri < ce && ((r >> 2) & (NT - 1)) == tl)
+                    st_off<float>(orowp, (unsigned)ri * 4u, diag);
             }
             wfin_b = w + 1;
             wfin_e = (nextB == p.n_prev) ? we : w + 1;
@@ -875,7 +879,7 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         a.slot_off = static_cast<int>(lds_stage / sizeof(float));
         const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
-        const int max_cpt = stg_inst <= 8 ? 24 : 16;
+        const int max_cpt = stg_inst <= 6 ? 24 : (stg_inst == 8 ? (s.pos_ord ? 24 : 20) : 16);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
         a.chunk_cols = (cpt + 3) / 4 * 4 * nt;                          // whole quads of columns per thread
