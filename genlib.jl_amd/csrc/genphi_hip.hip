@@ -307,7 +307,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     bool stage_is_a = true;
     bool have_next = nxt_l < len;
     unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
+    // columns [n, ld) (the "none" column and the pitch padding) are written as part of the
+    // last chunk: their padded index words point at the zero column, so they come out as 0
+    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
 
 #pragma unroll
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
@@ -466,7 +468,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.n);
+            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
         }
     }
 }
@@ -546,15 +548,6 @@ __global__ void half_identity_kernel(float *m, long long ld, int n, const int *o
     const int r = row_begin + k;                 // matrix row
     const long long orow = out_rows ? out_rows[k] : r;
     if (r < n) m[orow * ld + r] = 0.5f;
-}
-
-// zero columns [n, ld) of n_rows rows (the "none" column of a level and its pitch padding)
-__global__ void zero_cols_kernel(float *out, long long ld, int n, int n_rows)
-{
-    const int w = static_cast<int>(ld) - n;                       // <= 64 columns
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long r = idx / w;
-    if (r < n_rows) out[r * ld + n + (idx - r * w)] = 0.f;
 }
 
 // out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
@@ -877,7 +870,7 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
         const size_t lds = lds_stage + 16;
         a.slot_off = static_cast<int>(lds_stage / sizeof(float));
-        const int per_thread = static_cast<int>((s.n + nt - 1) / nt);
+        const int per_thread = static_cast<int>((s.ld + nt - 1) / nt);       // the padding columns [n, ld) are written too
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
         const int max_cpt = stg_inst <= 6 ? 24 : (stg_inst == 8 ? (s.pos_ord ? 24 : 20) : 16);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
@@ -912,14 +905,6 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         }
 #undef GENPHI_LAUNCH_SPLIT2
 #undef GENPHI_LAUNCH_SPLIT1
-        // zero columns [n, ld) of the rows just written (the "none" column and the pitch padding);
-        // kept out of the kernel, where it cost registers inside the per-child loop
-        if (s.ld > s.n) {
-            const int64_t out_rows_n = out_rows ? n_rows : s.n;
-            const long long cells = static_cast<long long>(out_rows_n) * (s.ld - s.n);
-            hipLaunchKernelGGL(zero_cols_kernel, dim3(static_cast<unsigned>((cells + 255) / 256)), dim3(256), 0, p->stream,
-                               out, static_cast<long long>(s.ld), static_cast<int>(s.n), static_cast<int>(out_rows_n));
-        }
     } else {
         int wmax = 0;
         for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
