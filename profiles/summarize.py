@@ -22,7 +22,7 @@ dst = os.path.join(root, "profiles")
 
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern))[0]
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)     # newest run in that directory
 
 
 shutil.copy(one("kt/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
