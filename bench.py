@@ -248,7 +248,7 @@ def main():
                          "whole_step_frac": (pl.algorithmic_bytes / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if kernel_ms > 0 else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
         print(json.dumps(out), flush=True)
     pl.close()

@@ -40,7 +40,7 @@ class GenphiStats(C.Structure):
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode",
     "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
-    "genphi_result_to_host", "genphi_compute_f32", "genphi_plan_destroy", "genphi_last_error",
+    "genphi_result_to_host", "genphi_result_sums", "genphi_compute_f32", "genphi_plan_destroy", "genphi_last_error",
     "genphi_version",
 ]
 
@@ -79,6 +79,8 @@ def lib():
         L.genphi_result_device.restype = C.c_int
         L.genphi_result_to_host.argtypes = [C.c_void_p, _F32P]
         L.genphi_result_to_host.restype = C.c_int
+        L.genphi_result_sums.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), _I64P]
+        L.genphi_result_sums.restype = C.c_int
         L.genphi_compute_f32.argtypes = [C.c_void_p, _F32P, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
         L.genphi_compute_f32.restype = C.c_int
         L.genphi_plan_destroy.argtypes = [C.c_void_p]
@@ -191,6 +193,23 @@ class PhiPlan:
         if rc:
             _raise(rc)
         return out
+
+    def result_sums(self):
+        """(sum of all resident entries, sum of their diagonal entries, resident rows), Float64,
+        reduced on the device."""
+        a, d, nr = C.c_double(), C.c_double(), C.c_int64()
+        rc = lib().genphi_result_sums(self._h, C.byref(a), C.byref(d), C.byref(nr))
+        if rc:
+            _raise(rc)
+        return a.value, d.value, nr.value
+
+    def phi_mean(self):
+        """gen.phiMean of the resident (full) result without a device-to-host copy."""
+        a, d, nr = self.result_sums()
+        n = self.n_probands
+        if nr != n:
+            raise ValueError("phi_mean needs all rows resident; combine result_sums() of the shards instead")
+        return np.float32((a - d) / (n * n - n))
 
     def compute(self, device=None, kernel=0, rows=None, timing=False):
         self.compute_device(device=device, kernel=kernel, rows=rows, timing=timing)

@@ -550,6 +550,27 @@ __global__ void half_identity_kernel(float *m, long long ld, int n, const int *o
     if (r < n) m[orow * ld + r] = 0.5f;
 }
 
+// phiMean support: Float64 sum of each resident row and its diagonal entry (row r0 + k holds
+// proband r0 + k).  One workgroup per row, fixed summation order => reproducible.
+__global__ void row_sums_kernel(const float *m, long long ld, int n, int row_begin, double *row_sum, double *diag)
+{
+    __shared__ double part[256];
+    const int k = blockIdx.x;
+    const float *row = m + (long long)k * ld;
+    double acc = 0.0;
+    for (int j = threadIdx.x * 4; j < n; j += blockDim.x * 4) {       // ld is a multiple of 64 and columns >= n are zero
+        const float4 v = *reinterpret_cast<const float4 *>(row + j);
+        acc += (static_cast<double>(v.x) + static_cast<double>(v.y)) + (static_cast<double>(v.z) + static_cast<double>(v.w));
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = blockDim.x >> 1; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { row_sum[k] = part[0]; diag[k] = static_cast<double>(row[row_begin + k]); }
+}
+
 // out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
 __global__ void colperm_kernel(const float *in, float *out, long long ld, int n, const int *perm)
 {
@@ -1095,6 +1116,34 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     HIP_TRY(hipMemcpy2DAsync(out, N * sizeof(float), p->result, static_cast<size_t>(p->res_ld) * sizeof(float),
                              N * sizeof(float), static_cast<size_t>(p->res_n_rows), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    return GENPHI_OK;
+}
+
+int genphi_result_sums(genphi_plan *p, double *sum_all, double *sum_diag, int64_t *n_rows_out)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (sum_all) *sum_all = 0.0;
+    if (sum_diag) *sum_diag = 0.0;
+    if (n_rows_out) *n_rows_out = p->res_n_rows;
+    if (p->res_n_rows == 0 || p->plan.n_pro == 0) return GENPHI_OK;
+    if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t nr = p->res_n_rows;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 2 * nr * sizeof(double)));
+    hipLaunchKernelGGL(row_sums_kernel, dim3(static_cast<unsigned>(nr)), dim3(256), 0, p->stream, p->result,
+                       static_cast<long long>(p->res_ld), static_cast<int>(p->plan.n_pro), static_cast<int>(p->res_row_begin),
+                       d, d + nr);
+    hipError_t e = hipGetLastError();
+    std::vector<double> h(2 * nr);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, 2 * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_sums: ") + hipGetErrorString(e));
+    double sa = 0.0, sd = 0.0;                      // fixed order: reproducible
+    for (int64_t k = 0; k < nr; ++k) { sa += h[k]; sd += h[nr + k]; }
+    if (sum_all) *sum_all = sa;
+    if (sum_diag) *sum_diag = sd;
     return GENPHI_OK;
 }
 

@@ -108,6 +108,13 @@ int genphi_result_device(const genphi_plan *plan, const float **d_ptr, int64_t *
  * can be passed directly when all rows were computed).                                       */
 int genphi_result_to_host(genphi_plan *plan, float *out);
 
+/* On-device reduction for phiMean(::Matrix{Float32}) (src/compute.jl:454-459) without moving the
+ * matrix to the host: Float64 sum of all resident entries and of their diagonal entries.
+ * mean off-diagonal kinship = (sum_all - sum_diag) / (N*N - N); with row shards the ranks add
+ * their partial sums.  The reference accumulates in Float32 (Julia's pairwise sum), so its
+ * value agrees to Float32 rounding, exactly when the sums are exact (geneaJi: 0.171875).      */
+int genphi_result_sums(genphi_plan *plan, double *sum_all, double *sum_diag, int64_t *n_rows);
+
 /* Convenience = genphi_compute_device + genphi_result_to_host: what the Julia shim's
  * phi(...; compute=true) calls.  out: N x N Float32, caller-owned.                           */
 int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,

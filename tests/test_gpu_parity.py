@@ -156,3 +156,28 @@ def test_properties_at_scale(gen):
     d = a.diagonal()
     assert d.min() >= 0.5 and d.max() < 1.0
     assert a.min() >= 0.0 and (a - np.diag(d)).max() <= 0.5
+
+
+def test_phi_mean_on_device(gen, oracle):
+    """phiMean reduced on the device (no 40 GB device-to-host copy)."""
+    ped = gen.genealogy(gen.geneaJi)
+    pl = gen.plan(ped)
+    phi = pl.compute()
+    assert float(pl.phi_mean()) == GOLD["geneaJi"]["phiMean"]            # test/runtests.jl:53, exact
+    a, d, nr = pl.result_sums()
+    assert a == float(phi.astype(np.float64).sum()) and d == float(np.trace(phi.astype(np.float64))) and nr == 3
+    pl.close()
+    ped = gen.genealogy(gen.genea140)
+    pl = gen.plan(ped)
+    phi = pl.compute()
+    g = GOLD["genea140_survey_derived"]
+    a, d, _ = pl.result_sums()
+    assert abs(a - g["sum_all"]) <= 1e-12 * g["sum_all"] and abs(d - g["trace"]) <= 1e-12 * g["trace"]
+    assert abs(float(pl.phi_mean()) - float(gen.phiMean(phi))) <= 1e-9   # host Float32 mirror vs device Float64
+    # shards: partial sums add up
+    parts = []
+    for r in [(0, 60), (60, 140)]:
+        pl.compute_device(rows=r)
+        parts.append(pl.result_sums())
+    assert abs(sum(p[0] for p in parts) - a) <= 1e-12 * a and abs(sum(p[1] for p in parts) - d) <= 1e-12 * d
+    pl.close()
