@@ -233,8 +233,9 @@ def main():
             "metric": "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline",
             "value": value, "unit": "proband-pairs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64 accumulate over f32 storage", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(sizes),
+                       "arithmetic": "Float64 accumulation over Float32 level matrices (the reference's contract)",
                        "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes / 1e9,
                        "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
                        "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,

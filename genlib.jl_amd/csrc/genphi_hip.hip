@@ -98,6 +98,7 @@ struct LevelArgs {
     int n_chunks;            // SPLIT: column chunks per row (work item = sibling group x chunk)
     int n_groups;            // SPLIT: sibling groups (runs of equal A source in the work list)
     int slot_off;            // SPLIT: float offset in LDS of the two work-queue hand-over slots
+    int zero_row;            // !=0: this launch also zeroes the "none" row n of `out` (intermediate levels)
 };
 
 // ---- shared pieces of the row kernels --------------------------------------------------------
@@ -154,6 +155,11 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
     extern __shared__ float lds[];
     float *sA = lds;
     float *sB = lds + p.lds_row;
+    if (blockIdx.x == (unsigned)p.n_rows) {        // extra block: the all-zero "none" row of this level
+        float *zr = p.out + (long long)p.n * p.ld;
+        for (long long j = threadIdx.x; j < p.ld; j += blockDim.x) zr[j] = 0.f;
+        return;
+    }
     const RowCtx r = row_setup(p);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nvec = p.lds_row >> 2;               // columns [0, lds_row) include the zero column
@@ -269,6 +275,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     const int q = n_items >> 3, rem = n_items & 7;
     const int begin = xcd * q + min(xcd, rem);
     const int len = q + (xcd < rem ? 1 : 0);
+    if (p.zero_row && blockIdx.x == 0) {                  // the all-zero "none" row of this level
+        float *zr = p.out + (long long)p.n * p.ld;
+        for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
+    }
     int *slot = reinterpret_cast<int *>(lds + p.slot_off);
     if (threadIdx.x == 0) {
         slot[0] = atomicAdd(&queue[xcd], 1);
@@ -693,9 +703,13 @@ int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
     *out = nullptr;
     genphi_plan *p = new (std::nothrow) genphi_plan();
     if (!p) return fail(GENPHI_ERR_ALLOC, "out of memory");
-    if (const char *env = std::getenv("GENPHI_LDS_CAP_FLOATS")) {   // test hook: force HALF mode on small inputs
+    if (const char *env = std::getenv("GENPHI_LDS_CAP_FLOATS")) {   // test hook: force SPLIT / HALF mode on small inputs
         const long v = std::atol(env);
         if (v >= 16) p->popt.lds_cap_floats = static_cast<int32_t>(v);
+    }
+    if (const char *env = std::getenv("GENPHI_FULL_MAX_FLOATS")) {  // tuning hook: FULL vs SPLIT threshold
+        const long v = std::atol(env);
+        if (v >= 0) p->popt.full_max_floats = static_cast<int32_t>(v);
     }
     std::string err;
     int rc;
@@ -846,6 +860,32 @@ static hipError_t set_max_lds(const void *fn, size_t bytes)
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
+// ---- SPLIT kernel instantiation table ---------------------------------------------------------
+template <int C, int S, bool O>
+static hipError_t launch_split_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
+                                    const int2 *grp, int *queue)
+{
+    hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_kernel<1024, C, S, O>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((level_split_kernel<1024, C, S, O>), dim3(grid), dim3(1024), lds, stream, a, desc, grp, queue);
+    return hipGetLastError();
+}
+
+template <bool O>
+static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
+                               const int4 *desc, const int2 *grp, int *queue)
+{
+#define GENPHI_T(C, S) if (cpt <= C && stg == S) return launch_split_inst<C, S, O>(grid, lds, stream, a, desc, grp, queue)
+    GENPHI_T(8, 2); GENPHI_T(16, 2); GENPHI_T(24, 2);
+    GENPHI_T(8, 4); GENPHI_T(16, 4); GENPHI_T(24, 4);
+    GENPHI_T(8, 6); GENPHI_T(16, 6); GENPHI_T(20, 6); GENPHI_T(24, 6);
+    GENPHI_T(8, 8); GENPHI_T(16, 8); GENPHI_T(20, 8);
+    if constexpr (O) { GENPHI_T(24, 8); }
+    GENPHI_T(8, 9); GENPHI_T(16, 9);
+#undef GENPHI_T
+    return hipErrorInvalidValue;
+}
+
 static int block_size_for(int64_t n)
 {
     if (n <= 512) return 64;
@@ -866,6 +906,7 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
     a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
     a.segs = d.segs; a.b_rel = d.b_rel; a.n_segs = static_cast<int>(s.segs.size());
     a.lds_row = 0; a.chunk_cols = 0;
+    a.zero_row = (out_rows == nullptr && kernel != 1 && s.mode != genphi::kModeHalf) ? 1 : 0;
     if (n_rows <= 0) return GENPHI_OK;
     const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
     if (kernel == 1) {
@@ -877,16 +918,17 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         const int bs = block_size_for(std::max(s.n, s.n_prev));
         if (s.pos_ord) {
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, true>), lds));
-            hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows), dim3(bs), lds, p->stream, a);
+            hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows + a.zero_row), dim3(bs), lds, p->stream, a);
         } else {
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, false>), lds));
-            hipLaunchKernelGGL((level_full_kernel<4, false>), dim3(n_rows), dim3(bs), lds, p->stream, a);
+            hipLaunchKernelGGL((level_full_kernel<4, false>), dim3(n_rows + a.zero_row), dim3(bs), lds, p->stream, a);
         }
     } else if (s.mode == genphi::kModeSplit) {
         a.lds_row = lds_row;
         constexpr int nt = 1024;
         const int stg = (lds_row / 4 + nt - 1) / nt;                 // float4 per thread per staged row
-        const int stg_inst = stg <= 6 ? 6 : (stg <= 8 ? 8 : 9);    // planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
+        // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
+        const int stg_inst = stg <= 2 ? 2 : (stg <= 4 ? 4 : (stg <= 6 ? 6 : (stg <= 8 ? 8 : 9)));
         // LDS must also absorb the unconditional over-write past the row's end
         const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
         const size_t lds = lds_stage + 16;
@@ -902,30 +944,8 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         const long long n_items = static_cast<long long>(n_groups) * n_chunks;
         const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
         int *queue = p->d_queues + 8 * step;                                  // zeroed at the start of the sweep
-#define GENPHI_LAUNCH_SPLIT2(C, S, O)                                                                \
-        do {                                                                                         \
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_split_kernel<nt, C, S, O>), lds)); \
-            hipLaunchKernelGGL((level_split_kernel<nt, C, S, O>), dim3(grid), dim3(nt), lds, p->stream, a, desc, grp, queue); \
-        } while (0)
-#define GENPHI_LAUNCH_SPLIT1(C, O)                                                                   \
-        do {                                                                                         \
-            if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(C, 6, O);                                        \
-            else if (stg_inst == 8) GENPHI_LAUNCH_SPLIT2(C, 8, O);                                   \
-            else GENPHI_LAUNCH_SPLIT2(C, 9, O);                                                      \
-        } while (0)
-        if (s.pos_ord) {
-            if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, true);
-            else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, true);
-            else if (cpt <= 20) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(20, 6, true); else GENPHI_LAUNCH_SPLIT2(20, 8, true); }
-            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, true); else GENPHI_LAUNCH_SPLIT2(24, 8, true); }
-        } else {
-            if (cpt <= 8) GENPHI_LAUNCH_SPLIT1(8, false);
-            else if (cpt <= 16) GENPHI_LAUNCH_SPLIT1(16, false);
-            else if (cpt <= 20) { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(20, 6, false); else GENPHI_LAUNCH_SPLIT2(20, 8, false); }
-            else { if (stg_inst == 6) GENPHI_LAUNCH_SPLIT2(24, 6, false); else GENPHI_LAUNCH_SPLIT2(24, 8, false); }
-        }
-#undef GENPHI_LAUNCH_SPLIT2
-#undef GENPHI_LAUNCH_SPLIT1
+        HIP_TRY(s.pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, p->stream, a, desc, grp, queue)
+                          : launch_split<false>(cpt, stg_inst, grid, lds, p->stream, a, desc, grp, queue));
     } else {
         int wmax = 0;
         for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
@@ -1056,8 +1076,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
                                   p->dsteps[s].desc, p->dsteps[s].grp, p->dsteps[s].n_groups);
                 if (rc) return rc;
-                // the all-zero "none" row of this level
-                HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
+                // the all-zero "none" row of this level (FULL / SPLIT kernels write it themselves)
+                if (kernel == 1 || st.mode == genphi::kModeHalf)
+                    HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
             } else {
                 float *out = need_perm ? p->final_tmp : p->result;
                 rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel,

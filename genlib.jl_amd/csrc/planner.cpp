@@ -186,7 +186,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     auto is_dragged = [&](int32_t x, int32_t c) { return tlast[x] > L - 1 - c; };
     auto step_mode = [&](int32_t c_prev) {      // step c_prev -> c_prev+1
         const int64_t lds_row = (plan.cut_sizes[c_prev] + 1 + 3) / 4 * 4;
-        if (2 * lds_row <= opt.lds_cap_floats) return int(kModeFull);
+        if (2 * lds_row <= opt.lds_cap_floats && lds_row <= opt.full_max_floats) return int(kModeFull);
         if (lds_row <= opt.lds_cap_floats && plan.cut_sizes[c_prev] < 65535) return int(kModeSplit);
         return int(kModeHalf);
     };
