@@ -364,7 +364,9 @@ int oracle_phi_compute(oracle_ped *p, const oracle_levels *lv, float *out,
         const int64_t n = next.n;
         float *phi = (float *)malloc((size_t)(n * n + 1) * sizeof(float));                     /* :291 */
         if (!phi) { free(Psi); return ORACLE_ERR_ALLOC; }
-        #pragma omp parallel for schedule(dynamic, 8)
+        /* threads only where a level is big enough to pay for the fork/join (deep pedigrees have
+         * hundreds of tiny levels; the reference's Threads.@threads has the same per-level cost) */
+        #pragma omp parallel for schedule(dynamic, 8) if (n >= 512)
         for (int64_t i = 0; i < n; i++) {                          /* :293-299 */
             for (int64_t j = i; j < n; j++) {
                 float v = (float)level_rec(p, next.v[i], next.v[j], Psi, ld);  /* Float64 -> Float32 RN */

@@ -181,3 +181,53 @@ def test_phi_mean_on_device(gen, oracle):
         parts.append(pl.result_sums())
     assert abs(sum(p[0] for p in parts) - a) <= 1e-12 * a and abs(sum(p[1] for p in parts) - d) <= 1e-12 * d
     pl.close()
+
+
+def _random_pedigree(rng, n, p_founder, p_one_parent, p_selfing, max_back):
+    """Arbitrary pedigree in id order (parents have smaller ids): overlapping generations,
+    one-parent individuals, founders anywhere, occasional selfing, sex not enforced."""
+    ind = np.arange(1, n + 1, dtype=np.int64)
+    fa = np.zeros(n, dtype=np.int64)
+    mo = np.zeros(n, dtype=np.int64)
+    for i in range(1, n):
+        if rng.random() < p_founder:
+            continue
+        lo = max(0, i - max_back)
+        f = int(rng.integers(lo, i)) + 1
+        m = int(rng.integers(lo, i)) + 1
+        r = rng.random()
+        if r < p_one_parent / 2:
+            f = 0
+        elif r < p_one_parent:
+            m = 0
+        elif rng.random() < p_selfing:
+            m = f
+        fa[i], mo[i] = f, m
+    return ind, fa, mo, np.ones(n, dtype=np.int64)
+
+
+def test_random_pedigrees_bit_exact(gen, oracle, monkeypatch):
+    """Randomised structures the synthetic shapes never produce, through every kernel mode."""
+    rng = np.random.default_rng(20241016)
+    cases = 0
+    for cap in (None, 640, 200):
+        if cap is None:
+            monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS", raising=False)
+        else:
+            monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+        for n, pf, p1, ps, back in [(60, 0.2, 0.2, 0.1, 8), (400, 0.05, 0.1, 0.02, 40), (1500, 0.02, 0.05, 0.0, 300),
+                                    (1500, 0.3, 0.3, 0.05, 1500), (800, 0.01, 0.0, 0.0, 60)]:
+            ind, fa, mo, sex = _random_pedigree(rng, n, pf, p1, ps, back)
+            oped = oracle.Pedigree(ind, fa, mo)
+            ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+            assert np.array_equal(ped.ind, oped.ind)
+            for pro in (None, rng.choice(ind, size=min(n, 37), replace=True)):
+                pro = oped.pro() if pro is None else pro
+                pl = gen.plan(ped, pro)
+                sizes, both = pl.levels()
+                osz, obo, _ = oped.levels(pro)
+                assert sizes == osz and both == obo
+                _assert_equal(pl.compute(), oped.phi(pro))
+                pl.close()
+                cases += 1
+    assert cases == 30
