@@ -34,6 +34,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/genphi.h"
@@ -1134,9 +1135,34 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
     HIP_TRY(hipSetDevice(p->device));
     const size_t N = static_cast<size_t>(p->plan.n_pro);
-    HIP_TRY(hipMemcpy2DAsync(out, N * sizeof(float), p->result, static_cast<size_t>(p->res_ld) * sizeof(float),
-                             N * sizeof(float), static_cast<size_t>(p->res_n_rows), hipMemcpyDeviceToHost, p->stream));
+    const size_t rows = static_cast<size_t>(p->res_n_rows);
     HIP_TRY(hipStreamSynchronize(p->stream));
+    // Large results: several host threads copy row blocks concurrently (pageable destination:
+    // one thread's staged copy runs at ~17 GB/s, far below the PCIe Gen5 link).
+    const size_t bytes = rows * N * sizeof(float);
+    int n_thr = 1;
+    if (bytes >= (size_t(256) << 20)) {
+        n_thr = 8;
+        if (const char *env = std::getenv("GENPHI_D2H_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(env)));
+    }
+    std::vector<hipError_t> errs(n_thr, hipSuccess);
+    auto copy_block = [&](int t) {
+        const size_t r0 = rows * t / n_thr, r1 = rows * (t + 1) / n_thr;
+        if (r1 == r0) return;
+        hipError_t e = hipSetDevice(p->device);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(out + r0 * N, N * sizeof(float), p->result + r0 * static_cast<size_t>(p->res_ld),
+                            static_cast<size_t>(p->res_ld) * sizeof(float), N * sizeof(float), r1 - r0, hipMemcpyDeviceToHost);
+        errs[t] = e;
+    };
+    if (n_thr == 1) copy_block(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t) th.emplace_back(copy_block, t);
+        for (auto &x : th) x.join();
+    }
+    for (hipError_t e : errs)
+        if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_to_host: ") + hipGetErrorString(e));
     return GENPHI_OK;
 }
 
