@@ -659,6 +659,9 @@ struct genphi_plan {
     int *d_final_perm = nullptr;
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
     int *d_queues = nullptr;        // 8 work-queue counters per level step
+    hipGraphExec_t graph_exec = nullptr;   // captured sweep (see genphi_compute_device)
+    long long graph_key[4] = {0, 0, 0, 0}, eager_key[4] = {0, 0, 0, 0};
+    bool eager_valid = false;
     int4 *d_shard_desc = nullptr;
     int2 *d_shard_grp = nullptr;
     int shard_groups = 0;
@@ -678,6 +681,8 @@ static void free_device(genphi_plan *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     p->events.clear();
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    p->eager_valid = false;
     (void)hipFree(p->idx_blob);
     (void)hipFree(p->d_shard_rows);
     (void)hipFree(p->d_shard_out_rows);
@@ -1051,50 +1056,84 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         p->shard_r0 = r0; p->shard_r1 = r1;
     }
 
-    if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
-    HIP_TRY(hipMemsetAsync(p->d_queues, 0, (pl.steps.size() + 1) * 8 * sizeof(int), p->stream));
-    if (n_steps == 0) {
-        // all probands parentless: result = 1/2 I (src/compute.jl:271-274, loop skipped)
-        HIP_TRY(hipMemsetAsync(p->result, 0, static_cast<size_t>(n_rows * ldN) * sizeof(float), p->stream));
-        hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0,
-                           p->stream, p->result, ldN, static_cast<int>(N), p->d_shard_out_rows,
-                           static_cast<int>(n_rows), static_cast<int>(r0));
-        HIP_TRY(hipGetLastError());
-    } else {
-        // Psi_1 = 1/2 I over the top founders
-        const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
-        HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
-        hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
-                           p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
-                           static_cast<int>(n0), 0);
-        HIP_TRY(hipGetLastError());
-        for (int s = 0; s < n_steps; ++s) {
-            const LevelStep &st = pl.steps[s];
-            const float *psi = p->buf[s & 1];
-            const bool last = s == n_steps - 1;
-            if (!last) {
-                float *out = p->buf[(s + 1) & 1];
-                rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
-                                  p->dsteps[s].desc, p->dsteps[s].grp, p->dsteps[s].n_groups);
-                if (rc) return rc;
-                // the all-zero "none" row of this level (FULL / SPLIT kernels write it themselves)
-                if (kernel == 1 || st.mode == genphi::kModeHalf)
-                    HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
-            } else {
-                float *out = need_perm ? p->final_tmp : p->result;
-                rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel,
-                                  p->d_shard_desc, p->d_shard_grp, p->shard_groups);
-                if (rc) return rc;
-                if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
-                if (need_perm) {
-                    dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((ldN + 255) / 256));
-                    hipLaunchKernelGGL(colperm_kernel, grid, dim3(256), 0, p->stream, p->final_tmp, p->result, ldN,
-                                       static_cast<int>(N), p->d_final_perm);
-                    HIP_TRY(hipGetLastError());
+    // ---- the sweep: every launch of one gen.phi, in stream order ------------------------------
+    auto enqueue = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(p->d_queues, 0, (pl.steps.size() + 1) * 8 * sizeof(int), p->stream));
+        if (n_steps == 0) {
+            // all probands parentless: result = 1/2 I (src/compute.jl:271-274, loop skipped)
+            HIP_TRY(hipMemsetAsync(p->result, 0, static_cast<size_t>(n_rows * ldN) * sizeof(float), p->stream));
+            hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0,
+                               p->stream, p->result, ldN, static_cast<int>(N), p->d_shard_out_rows,
+                               static_cast<int>(n_rows), static_cast<int>(r0));
+            HIP_TRY(hipGetLastError());
+        } else {
+            // Psi_1 = 1/2 I over the top founders
+            const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
+            HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
+            hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
+                               p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
+                               static_cast<int>(n0), 0);
+            HIP_TRY(hipGetLastError());
+            for (int s = 0; s < n_steps; ++s) {
+                const LevelStep &st = pl.steps[s];
+                const float *psi = p->buf[s & 1];
+                const bool last = s == n_steps - 1;
+                if (!last) {
+                    float *out = p->buf[(s + 1) & 1];
+                    rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
+                                      p->dsteps[s].desc, p->dsteps[s].grp, p->dsteps[s].n_groups);
+                    if (rc) return rc;
+                    // the all-zero "none" row of this level (FULL / SPLIT kernels write it themselves)
+                    if (kernel == 1 || st.mode == genphi::kModeHalf)
+                        HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
+                } else {
+                    float *out = need_perm ? p->final_tmp : p->result;
+                    rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel,
+                                      p->d_shard_desc, p->d_shard_grp, p->shard_groups);
+                    if (rc) return rc;
+                    if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
+                    if (need_perm) {
+                        dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((ldN + 255) / 256));
+                        hipLaunchKernelGGL(colperm_kernel, grid, dim3(256), 0, p->stream, p->final_tmp, p->result, ldN,
+                                           static_cast<int>(N), p->d_final_perm);
+                        HIP_TRY(hipGetLastError());
+                    }
                 }
+                if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
             }
-            if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
         }
+        return GENPHI_OK;
+    };
+
+    // A sweep is 1 + L-1 small launches; deep pedigrees (hundreds of tiny levels) are bound by
+    // launch overhead.  After one eager run with the same arguments (which sizes buffers and
+    // opts kernels into their LDS), the sweep is captured into a hipGraph and replayed.
+    // Timing runs stay eager (they need events between the launches).
+    static const bool graphs_off = std::getenv("GENPHI_NO_GRAPH") != nullptr;
+    const long long key[4] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0};
+    const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
+    const bool use_graph = !timing && !graphs_off && !(opts && (opts->reserved & 1)) && same_as_eager && n_steps >= 8;
+    if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
+    if (use_graph) {
+        if (!p->graph_exec || std::memcmp(key, p->graph_key, sizeof(key)) != 0) {
+            if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+            HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+            const int erc = enqueue();
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(p->stream, &graph);
+            if (erc != GENPHI_OK) { if (graph) (void)hipGraphDestroy(graph); return erc; }
+            if (ce != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            const hipError_t ie = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { p->graph_exec = nullptr; return fail(GENPHI_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            std::memcpy(p->graph_key, key, sizeof(key));
+        }
+        HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+    } else {
+        rc = enqueue();
+        if (rc) return rc;
+        std::memcpy(p->eager_key, key, sizeof(key));
+        p->eager_valid = true;
     }
     if (timing && n_steps == 0) HIP_TRY(hipEventRecord(p->events[1], p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));

@@ -231,3 +231,24 @@ def test_random_pedigrees_bit_exact(gen, oracle, monkeypatch):
                 pl.close()
                 cases += 1
     assert cases == 30
+
+
+def test_graph_replay_matches_eager(gen, oracle):
+    """The sweep is replayed from a captured hipGraph from the second untimed compute on:
+    results must not change, also after switching shard / kernel and back."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.deep_inbred(120, 40, 3)
+    ref = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    for _ in range(4):                                   # eager, capture + replay, replay, replay
+        _assert_equal(pl.compute(), ref)
+    _assert_equal(pl.compute(rows=(5, 17)), ref[5:17])   # new key: eager again
+    _assert_equal(pl.compute(rows=(5, 17)), ref[5:17])   # captured for the shard
+    _assert_equal(pl.compute(kernel=1), ref)
+    _assert_equal(pl.compute(), ref)
+    _assert_equal(pl.compute(), ref)
+    st = pl.compute_device(timing=True)                  # timing runs stay eager
+    assert st.timed == 1 and st.n_steps == len(pl.levels()[0]) - 1
+    _assert_equal(pl.result_to_host(), ref)
+    pl.close()
