@@ -252,3 +252,36 @@ def test_graph_replay_matches_eager(gen, oracle):
     assert st.timed == 1 and st.n_steps == len(pl.levels()[0]) - 1
     _assert_equal(pl.result_to_host(), ref)
     pl.close()
+
+
+def test_full_size_cfg4_properties(gen):
+    """BASELINE.json's headline size (1e6 individuals / 1e5 probands / 30 generations): far too
+    big for the oracle, so check size-independent properties of the 40 GB result without moving
+    it to the host: (i) the Float64 row-sum checksums of the pipelined kernel and of the naive
+    one-thread-per-entry kernel are bit-identical; (ii) shard checksums add up to the full one;
+    (iii) symmetry and diagonal range on sampled row blocks fetched through the shard API."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(1_000_000, 100_000, 30)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    n = pl.n_probands
+    assert n == 100_000 and set(pl.step_modes()) == {1}           # every level through the SPLIT kernel
+    pl.compute_device()
+    full = pl.result_sums()
+    mean = float(pl.phi_mean())
+    assert 0.0 < mean < 0.01
+    pl.compute_device(kernel=1)
+    assert pl.result_sums() == full                                # naive kernel: identical checksums
+    parts = []
+    for r in [(0, 30_000), (30_000, 30_001), (30_001, 100_000)]:
+        pl.compute_device(rows=r)
+        parts.append(pl.result_sums())
+    assert sum(p[2] for p in parts) == n
+    assert abs(sum(p[0] for p in parts) - full[0]) <= 1e-12 * full[0]
+    assert sum(p[1] for p in parts) == full[1]                     # diagonals are dyadic: exact in any order
+    a = pl.compute(rows=(1000, 1064))                              # (64, n)
+    b = pl.compute(rows=(77_000, 77_064))
+    assert np.array_equal(a[:, 77_000:77_064], b[:, 1000:1064].T)  # bit-symmetric
+    d = np.concatenate([a[np.arange(64), 1000 + np.arange(64)], b[np.arange(64), 77_000 + np.arange(64)]])
+    assert d.min() >= 0.5 and d.max() < 1.0 and a.min() >= 0.0 and a.max() < 1.0
+    pl.close()
