@@ -89,6 +89,9 @@ def genealogy(source, sort=True):
     `rank` the kinship recursion branches on.  With sort=False the input order is kept and a
     parent listed after its child raises KeyError, as `_finalize_pedigree` does.
     """
+    if isinstance(source, (str, os.PathLike)):
+        # files go through the native loader (parse + depth sort in C++, csrc/loader.cpp)
+        return Pedigree(*_capi.genealogy_read(source, sort=sort))
     ind, father, mother, sex = (np.ascontiguousarray(a, dtype=np.int64) for a in _read_table(source))
     n = len(ind)
     if len(np.unique(ind)) != n:

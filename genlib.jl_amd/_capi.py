@@ -40,7 +40,7 @@ class GenphiStats(C.Structure):
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode",
     "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
-    "genphi_result_to_host", "genphi_result_sums", "genphi_compute_f32", "genphi_plan_destroy", "genphi_last_error",
+    "genphi_result_to_host", "genphi_result_sums", "genphi_compute_f32", "genphi_genealogy_read", "genphi_free", "genphi_plan_destroy", "genphi_last_error",
     "genphi_version",
 ]
 
@@ -83,6 +83,11 @@ def lib():
         L.genphi_result_sums.restype = C.c_int
         L.genphi_compute_f32.argtypes = [C.c_void_p, _F32P, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
         L.genphi_compute_f32.restype = C.c_int
+        L.genphi_genealogy_read.argtypes = [C.c_char_p, C.c_int32, _I64P, C.POINTER(_I64P), C.POINTER(_I64P),
+                                            C.POINTER(_I64P), C.POINTER(_I64P)]
+        L.genphi_genealogy_read.restype = C.c_int
+        L.genphi_free.argtypes = [C.c_void_p]
+        L.genphi_free.restype = None
         L.genphi_plan_destroy.argtypes = [C.c_void_p]
         L.genphi_plan_destroy.restype = None
         L.genphi_last_error.restype = C.c_char_p
@@ -108,6 +113,22 @@ def _raise(rc):
 
 def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def genealogy_read(path, sort=True):
+    """(ind, father, mother, sex) int64 arrays in rank order, parsed and depth-sorted natively."""
+    L = lib()
+    n = C.c_int64()
+    ptrs = [_I64P() for _ in range(4)]
+    rc = L.genphi_genealogy_read(os.fsencode(path), 1 if sort else 0, C.byref(n), *[C.byref(p) for p in ptrs])
+    if rc:
+        _raise(rc)
+    try:
+        out = tuple(np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64) for p in ptrs)
+    finally:
+        for p in ptrs:
+            L.genphi_free(p)
+    return out
 
 
 class PhiPlan:

@@ -599,6 +599,7 @@ __global__ void colperm_kernel(const float *in, float *out, long long ld, int n,
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+int genphi_set_error(int code, const std::string &msg) { return fail(code, msg); }   // for loader.cpp
 
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \

@@ -120,6 +120,16 @@ int genphi_result_sums(genphi_plan *plan, double *sum_all, double *sum_diag, int
 int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,
                        genphi_stats *stats);
 
+/* Native loader for the step before the path: gen.genealogy(filename; sort) (src/create.jl:161-189:
+ * header row skipped, four whitespace-separated integers `ind father mother sex` per row) plus,
+ * with sort != 0, _ordered_pedigree (src/create.jl:196-227: stable sort by maximum ancestral
+ * depth).  Returns the pedigree in RANK ORDER, ready for genphi_plan_create, in arrays
+ * allocated by the library (release each with genphi_free).  sex_out may be NULL.  Unknown
+ * parent -> GENPHI_ERR_UNKNOWN_ID; sort == 0 and a parent after its child -> GENPHI_ERR_ORDER. */
+int genphi_genealogy_read(const char *path, int32_t sort, int64_t *n, int64_t **ind, int64_t **father,
+                          int64_t **mother, int64_t **sex_out);
+void genphi_free(void *ptr);
+
 /* Frees host and device memory of the plan (NULL is allowed). */
 void genphi_plan_destroy(genphi_plan *plan);
 

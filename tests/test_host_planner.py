@@ -135,3 +135,42 @@ def test_synthetic_generator_is_deterministic(gen):
     ind, fa, mo, sex, pro = a
     assert np.all(fa < ind) and np.all(mo < ind) and len(pro) == 100
     assert np.all(sex[fa[fa > 0] - 1] == 1) and np.all(sex[mo[mo > 0] - 1] == 2)
+
+
+def test_native_loader_matches_oracle_rank_order(gen, oracle, tmp_path):
+    """genphi_genealogy_read (csrc/loader.cpp) = gen.genealogy(filename; sort): TSV parse
+    (src/create.jl:161-189) + stable depth sort (:196-227), against the oracle's restatement."""
+    from genlib_jl_amd import synth, _capi
+    for name in ("geneaJi.csv", "genea140.csv"):
+        path = os.path.join(HERE, "golden", name)
+        ind, fa, mo, sex = _capi.genealogy_read(path)
+        op = oracle.Pedigree.from_file(path)
+        assert np.array_equal(ind, op.ind) and np.array_equal(fa, op.father) and np.array_equal(mo, op.mother)
+    # shuffled file order: the depth sort has real work, ties keep file order
+    ind, fa, mo, sex, _ = synth.random_mating(50_000, 5_000, 12, skip_permille=80)
+    perm = np.random.default_rng(5).permutation(len(ind))
+    path = str(tmp_path / "shuffled.tsv")
+    synth.write_tsv(path, ind[perm], fa[perm], mo[perm], sex[perm])
+    got = _capi.genealogy_read(path)
+    op = oracle.Pedigree(ind[perm], fa[perm], mo[perm])
+    assert np.array_equal(got[0], op.ind) and np.array_equal(got[1], op.father) and np.array_equal(got[2], op.mother)
+    assert np.array_equal(np.sort(got[0]), np.sort(ind)) and set(np.unique(got[3])) <= {1, 2}
+    # sort=False keeps file order and requires parents first (KeyError otherwise, as _finalize_pedigree)
+    with pytest.raises(KeyError):
+        _capi.genealogy_read(path, sort=False)
+    ordered = str(tmp_path / "ordered.tsv")
+    synth.write_tsv(ordered, ind, fa, mo, sex)
+    assert np.array_equal(_capi.genealogy_read(ordered, sort=False)[0], ind)
+    # error behaviour
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("ind\tfather\tmother\tsex\n1\t0\t0\t1\n2\t1\t9\t2\n")
+    with pytest.raises(KeyError):
+        _capi.genealogy_read(str(bad))                 # unknown mother 9
+    bad.write_text("ind\tfather\tmother\tsex\n1\t0\t0\n")
+    with pytest.raises(ValueError):
+        _capi.genealogy_read(str(bad))                 # 3 columns
+    with pytest.raises(ValueError):
+        _capi.genealogy_read(str(tmp_path / "missing.tsv"))
+    bad.write_text("ind\tfather\tmother\tsex\n1\t2\t0\t1\n2\t1\t0\t1\n")
+    with pytest.raises(ValueError):
+        _capi.genealogy_read(str(bad))                 # cycle
