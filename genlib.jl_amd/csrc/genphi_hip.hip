@@ -886,7 +886,11 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
     GENPHI_T(8, 2); GENPHI_T(16, 2); GENPHI_T(24, 2);
     GENPHI_T(8, 4); GENPHI_T(16, 4); GENPHI_T(24, 4);
     GENPHI_T(8, 6); GENPHI_T(16, 6); GENPHI_T(20, 6); GENPHI_T(24, 6);
+    if constexpr (O) { GENPHI_T(28, 6); }
+    GENPHI_T(8, 7); GENPHI_T(16, 7); GENPHI_T(20, 7); GENPHI_T(24, 7);
+    if constexpr (O) { GENPHI_T(28, 7); }
     GENPHI_T(8, 8); GENPHI_T(16, 8); GENPHI_T(20, 8);
+    if constexpr (O) { GENPHI_T(24, 8); }
     if constexpr (O) { GENPHI_T(24, 8); }
     GENPHI_T(8, 9); GENPHI_T(16, 9);
 #undef GENPHI_T
@@ -935,14 +939,18 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         constexpr int nt = 1024;
         const int stg = (lds_row / 4 + nt - 1) / nt;                 // float4 per thread per staged row
         // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
-        const int stg_inst = stg <= 2 ? 2 : (stg <= 4 ? 4 : (stg <= 6 ? 6 : (stg <= 8 ? 8 : 9)));
+        const int stg_inst = stg <= 2 ? 2 : (stg <= 4 ? 4 : (stg <= 6 ? 6 : (stg <= 7 ? 7 : (stg <= 8 ? 8 : 9))));
         // LDS must also absorb the unconditional over-write past the row's end
         const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
         const size_t lds = lds_stage + 16;
         a.slot_off = static_cast<int>(lds_stage / sizeof(float));
         const int per_thread = static_cast<int>((s.ld + nt - 1) / nt);       // the padding columns [n, ld) are written too
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
-        const int max_cpt = stg_inst <= 6 ? 24 : (stg_inst == 8 ? (s.pos_ord ? 24 : 20) : 16);
+        // (columns per thread an instantiation affords without spilling; (28, 6, pos) spills one
+        //  VGPR in stage A only and still wins over two chunks)
+        int max_cpt;
+        if (s.pos_ord) max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 7 ? 28 : (stg_inst == 8 ? 24 : 16));
+        else           max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
         a.chunk_cols = (cpt + 3) / 4 * 4 * nt;                          // whole quads of columns per thread
