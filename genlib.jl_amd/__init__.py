@@ -180,6 +180,44 @@ def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, ker
         pl.close()
 
 
+def f(pedigree, IDs, device=None):
+    """gen.f(pedigree, IDs) (src/compute.jl:500-511): inbreeding coefficients (Float32 vector).
+
+    F(x) = kinship of x's parents, 0 if a parent is unknown.  The reference evaluates each one
+    with the un-memoised pairwise recursion (:66-95), exponential on deep inbred pedigrees;
+    here ONE level sweep over the set of parents runs on the GPU and the (father, mother)
+    entries are read back (`genphi_result_entries`).  The reference rounds the exact Float64
+    value to Float32 once; the sweep rounds to Float32 at every level, so the two agree to
+    ~3e-8 and exactly whenever no level rounds (geneaJi: f(ped, [1]) == [0.18359375],
+    f(ped, [17]) == [0.], test/runtests.jl:47-48).
+    """
+    IDs = np.asarray(IDs, dtype=np.int64)
+    pos = pedigree.positions(IDs)                       # KeyError on an unknown ID
+    fa, mo = pedigree.father[pos], pedigree.mother[pos]
+    out = np.zeros(len(IDs), dtype=np.float32)
+    both = (fa != 0) & (mo != 0)
+    if not np.any(both):
+        return out
+    parents = np.unique(np.concatenate([fa[both], mo[both]]))     # sorted, like a proband list
+    pl = plan(pedigree, parents)
+    try:
+        pl.compute_device(device=device)
+        out[both] = pl.result_entries(np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both]))
+    finally:
+        pl.close()
+    return out
+
+
+def branching(pedigree, pro=None, ancestors=None):
+    """gen.branching(pedigree; pro=nothing, ancestors=nothing) (src/extract.jl:65-186).
+
+    Pedigree of the individuals on the paths between the selected probands and ancestors
+    (host-side pruning before gen.phi; native, csrc/loader.cpp).  KeyError on an unknown ID.
+    """
+    return Pedigree(*_capi.branching(pedigree.ind, pedigree.father, pedigree.mother, pedigree.sex,
+                                     pro=pro, ancestors=ancestors))
+
+
 def phiMean(phi_matrix):
     """gen.phiMean(::Matrix{Float32}) (src/compute.jl:454-459): mean off-diagonal kinship,
     accumulated in float32 like the reference (host-side; an on-device reduction is a

@@ -40,7 +40,8 @@ class GenphiStats(C.Structure):
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode",
     "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
-    "genphi_result_to_host", "genphi_result_sums", "genphi_compute_f32", "genphi_genealogy_read", "genphi_free", "genphi_plan_destroy", "genphi_last_error",
+    "genphi_result_to_host", "genphi_result_sums", "genphi_result_entries", "genphi_compute_f32",
+    "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_destroy", "genphi_last_error",
     "genphi_version",
 ]
 
@@ -81,6 +82,11 @@ def lib():
         L.genphi_result_to_host.restype = C.c_int
         L.genphi_result_sums.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), _I64P]
         L.genphi_result_sums.restype = C.c_int
+        L.genphi_result_entries.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double)]
+        L.genphi_result_entries.restype = C.c_int
+        L.genphi_branching.argtypes = [C.c_int64, _I64P, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.c_int64, _I64P,
+                                       _I64P, C.POINTER(_I64P), C.POINTER(_I64P), C.POINTER(_I64P), C.POINTER(_I64P)]
+        L.genphi_branching.restype = C.c_int
         L.genphi_compute_f32.argtypes = [C.c_void_p, _F32P, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
         L.genphi_compute_f32.restype = C.c_int
         L.genphi_genealogy_read.argtypes = [C.c_char_p, C.c_int32, _I64P, C.POINTER(_I64P), C.POINTER(_I64P),
@@ -121,6 +127,32 @@ def genealogy_read(path, sort=True):
     n = C.c_int64()
     ptrs = [_I64P() for _ in range(4)]
     rc = L.genphi_genealogy_read(os.fsencode(path), 1 if sort else 0, C.byref(n), *[C.byref(p) for p in ptrs])
+    if rc:
+        _raise(rc)
+    try:
+        out = tuple(np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64) for p in ptrs)
+    finally:
+        for p in ptrs:
+            L.genphi_free(p)
+    return out
+
+
+def branching(ind, father, mother, sex, pro=None, ancestors=None):
+    """(ind, father, mother, sex) of the pruned pedigree, rank order kept (genphi_branching)."""
+    L = lib()
+    ind, father, mother, sex = _i64(ind), _i64(father), _i64(mother), _i64(sex)
+    pro_a = None if pro is None else _i64(pro)
+    anc_a = None if ancestors is None else _i64(ancestors)
+    # a zero-length "given" list must stay distinguishable from "not given" (NULL)
+    keep = np.zeros(1, dtype=np.int64)
+    ptr = lambda a: None if a is None else (a if len(a) else keep).ctypes.data_as(_I64P)  # noqa: E731
+    n = C.c_int64()
+    ptrs = [_I64P() for _ in range(4)]
+    rc = L.genphi_branching(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P),
+                            mother.ctypes.data_as(_I64P), sex.ctypes.data_as(_I64P),
+                            0 if pro_a is None else len(pro_a), ptr(pro_a),
+                            0 if anc_a is None else len(anc_a), ptr(anc_a),
+                            C.byref(n), *[C.byref(p) for p in ptrs])
     if rc:
         _raise(rc)
     try:
@@ -223,6 +255,18 @@ class PhiPlan:
         if rc:
             _raise(rc)
         return a.value, d.value, nr.value
+
+    def result_entries(self, rows, cols):
+        """Phi[rows[k], cols[k]] (0-based proband positions) read from the resident result, Float64."""
+        rows, cols = _i64(rows), _i64(cols)
+        if rows.shape != cols.shape or rows.ndim != 1:
+            raise ValueError("rows and cols must be 1-D and of equal length")
+        out = np.empty(len(rows), dtype=np.float64)
+        rc = lib().genphi_result_entries(self._h, len(rows), rows.ctypes.data_as(_I64P), cols.ctypes.data_as(_I64P),
+                                         out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc:
+            _raise(rc)
+        return out
 
     def phi_mean(self):
         """gen.phiMean of the resident (full) result without a device-to-host copy."""

@@ -561,6 +561,14 @@ __global__ void half_identity_kernel(float *m, long long ld, int n, const int *o
     if (r < n) m[orow * ld + r] = 0.5f;
 }
 
+// point lookups in the resident result (genphi_result_entries): out[k] = m[off[k]] widened
+__global__ void gather_entries_kernel(const float *__restrict__ m, const long long *__restrict__ off, long long n,
+                                      double *__restrict__ out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = static_cast<double>(m[off[k]]);
+}
+
 // phiMean support: Float64 sum of each resident row and its diagonal entry (row r0 + k holds
 // proband r0 + k).  One workgroup per row, fixed summation order => reproducible.
 __global__ void row_sums_kernel(const float *m, long long ld, int n, int row_begin, double *row_sum, double *diag)
@@ -951,6 +959,10 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         int max_cpt;
         if (s.pos_ord) max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 7 ? 28 : (stg_inst == 8 ? 24 : 16));
         else           max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
+        if (const char *e = std::getenv("GENPHI_MAX_CPT")) {                  // tuning hook: smaller chunks
+            const int v = std::atoi(e);
+            if (v >= 4) max_cpt = std::min(max_cpt, v / 4 * 4);
+        }
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
         a.chunk_cols = (cpt + 3) / 4 * 4 * nt;                          // whole quads of columns per thread
@@ -1239,6 +1251,39 @@ int genphi_result_sums(genphi_plan *p, double *sum_all, double *sum_diag, int64_
     for (int64_t k = 0; k < nr; ++k) { sa += h[k]; sd += h[nr + k]; }
     if (sum_all) *sum_all = sa;
     if (sum_diag) *sum_diag = sd;
+    return GENPHI_OK;
+}
+
+int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const int64_t *cols, double *out)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (n < 0 || (n > 0 && (!rows || !cols || !out))) return fail(GENPHI_ERR_ARG, "genphi_result_entries: bad argument");
+    if (n == 0) return GENPHI_OK;
+    if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
+    const int64_t N = p->plan.n_pro, r0 = p->res_row_begin, nr = p->res_n_rows;
+    std::vector<long long> off(static_cast<size_t>(n));
+    for (int64_t k = 0; k < n; ++k) {
+        if (rows[k] < r0 || rows[k] >= r0 + nr || cols[k] < 0 || cols[k] >= N)
+            return fail(GENPHI_ERR_ARG, "genphi_result_entries: entry (" + std::to_string(rows[k]) + ", " + std::to_string(cols[k]) +
+                                        ") outside the resident rows [" + std::to_string(r0) + ", " + std::to_string(r0 + nr) + ") x [0, " + std::to_string(N) + ")");
+        off[k] = static_cast<long long>(rows[k] - r0) * p->res_ld + cols[k];
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    long long *d_off = nullptr;
+    double *d_val = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), n * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_val), n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_entries_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, p->stream,
+                           p->result, d_off, n, d_val);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_val, n * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(d_off);
+    (void)hipFree(d_val);
+    if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_entries: ") + hipGetErrorString(e));
     return GENPHI_OK;
 }
 

@@ -1,4 +1,5 @@
-// loader.cpp -- native pedigree loader: the step BEFORE the gen.phi hot path.
+// loader.cpp -- native pedigree loader and pruning: the steps BEFORE the gen.phi hot path
+// (genealogy(filename) and branching).
 //
 // Replaces, for callers that want it, the reference's genealogy(filename; sort)
 // (src/create.jl:161-189: header line skipped, four whitespace-separated Ints per row) followed
@@ -138,6 +139,85 @@ int genphi_genealogy_read(const char *path, int32_t sort, int64_t *n_out, int64_
     int64_t *a = emit(c.ind), *b = emit(c.father), *d = emit(c.mother), *e = sex_out ? emit(c.sex) : nullptr;
     if (!a || !b || !d || (sex_out && !e)) { std::free(a); std::free(b); std::free(d); std::free(e); return genphi_set_error(GENPHI_ERR_ALLOC, "out of memory"); }
     *n_out = n; *ind_out = a; *father_out = b; *mother_out = d;
+    if (sex_out) *sex_out = e;
+    return GENPHI_OK;
+}
+
+// gen.branching (src/extract.jl:65-186).  The reference marks ancestors / descendants with two
+// recursive walks over a pointer graph; here the pedigree is already in rank order (parents
+// before children), so both marks are single linear passes: ancestors in one reverse sweep
+// (a marked child marks its parents), descendants in one forward sweep (a marked parent marks
+// its children).  No recursion, no per-individual allocation, O(N).
+int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                     const int64_t *sex, int64_t n_pro, const int64_t *pro, int64_t n_anc,
+                     const int64_t *ancestors, int64_t *n_out, int64_t **ind_out, int64_t **father_out,
+                     int64_t **mother_out, int64_t **sex_out)
+{
+    if (!n_out || !ind_out || !father_out || !mother_out || n_ind < 0 || (n_ind > 0 && (!ind || !father || !mother)) ||
+        n_pro < 0 || n_anc < 0)
+        return genphi_set_error(GENPHI_ERR_ARG, "genphi_branching: bad argument");
+    *n_out = 0; *ind_out = *father_out = *mother_out = nullptr;
+    if (sex_out) *sex_out = nullptr;
+    const int64_t n = n_ind;
+    std::unordered_map<int64_t, int64_t> pos;
+    pos.reserve(static_cast<size_t>(n) * 2);
+    for (int64_t i = 0; i < n; ++i)
+        if (!pos.emplace(ind[i], i).second)
+            return genphi_set_error(GENPHI_ERR_DUPLICATE_ID, "duplicate individual ID " + std::to_string(ind[i]));
+    std::vector<int64_t> pf(n, -1), pm(n, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int side = 0; side < 2; ++side) {
+            const int64_t pid = side ? mother[i] : father[i];
+            if (pid == 0) continue;
+            auto it = pos.find(pid);
+            if (it == pos.end()) return genphi_set_error(GENPHI_ERR_UNKNOWN_ID, "KeyError: parent " + std::to_string(pid) + " of " + std::to_string(ind[i]) + " not found");
+            if (it->second >= i) return genphi_set_error(GENPHI_ERR_ORDER, "KeyError: a parent of " + std::to_string(ind[i]) + " is listed after it");
+            (side ? pm : pf)[i] = it->second;
+        }
+    }
+    std::vector<uint8_t> is_anc(n, 0), is_desc(n, 0);
+    if (pro) {
+        for (int64_t k = 0; k < n_pro; ++k) {
+            auto it = pos.find(pro[k]);
+            if (it == pos.end()) return genphi_set_error(GENPHI_ERR_UNKNOWN_ID, "KeyError: proband " + std::to_string(pro[k]) + " not found");
+            is_anc[it->second] = 1;
+        }
+        for (int64_t i = n - 1; i >= 0; --i)
+            if (is_anc[i]) {
+                if (pf[i] >= 0) is_anc[pf[i]] = 1;
+                if (pm[i] >= 0) is_anc[pm[i]] = 1;
+            }
+    }
+    if (ancestors) {
+        for (int64_t k = 0; k < n_anc; ++k) {
+            auto it = pos.find(ancestors[k]);
+            if (it == pos.end()) return genphi_set_error(GENPHI_ERR_UNKNOWN_ID, "KeyError: ancestor " + std::to_string(ancestors[k]) + " not found");
+            is_desc[it->second] = 1;
+        }
+        for (int64_t i = 0; i < n; ++i)
+            if (!is_desc[i] && ((pf[i] >= 0 && is_desc[pf[i]]) || (pm[i] >= 0 && is_desc[pm[i]]))) is_desc[i] = 1;
+    }
+    // kept set; a parent outside it becomes unknown (only possible when `ancestors` is given)
+    std::vector<uint8_t> keep(n, 0);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        keep[i] = (pro && ancestors) ? (is_anc[i] && is_desc[i]) : (pro ? is_anc[i] : (ancestors ? is_desc[i] : 0));
+        m += keep[i];
+    }
+    const size_t bytes = sizeof(int64_t) * static_cast<size_t>(m > 0 ? m : 1);
+    int64_t *a = static_cast<int64_t *>(std::malloc(bytes)), *b = static_cast<int64_t *>(std::malloc(bytes));
+    int64_t *d = static_cast<int64_t *>(std::malloc(bytes)), *e = sex_out ? static_cast<int64_t *>(std::malloc(bytes)) : nullptr;
+    if (!a || !b || !d || (sex_out && !e)) { std::free(a); std::free(b); std::free(d); std::free(e); return genphi_set_error(GENPHI_ERR_ALLOC, "out of memory"); }
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!keep[i]) continue;
+        a[o] = ind[i];
+        b[o] = (pf[i] >= 0 && keep[pf[i]]) ? father[i] : 0;
+        d[o] = (pm[i] >= 0 && keep[pm[i]]) ? mother[i] : 0;
+        if (e) e[o] = sex ? sex[i] : 0;
+        ++o;
+    }
+    *n_out = m; *ind_out = a; *father_out = b; *mother_out = d;
     if (sex_out) *sex_out = e;
     return GENPHI_OK;
 }

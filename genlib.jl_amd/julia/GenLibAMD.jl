@@ -38,16 +38,24 @@ end
 Square `Matrix{Float32}` of pairwise kinship coefficients between probands, bit-identical to
 `GenLib.phi`, computed on an MI355X.
 """
-function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
-             verbose::Bool = false, compute::Bool = true, device::Integer = -1)
-    # flatten in rank order (the traversal of GenLib.genout, src/output.jl:24-29, kept at 64 bit)
+# flatten in rank order (the traversal of GenLib.genout, src/output.jl:24-29, kept at 64 bit)
+function flatten(pedigree::GenLib.Pedigree)
     n = length(pedigree)
     ind = Vector{Int64}(undef, n); father = zeros(Int64, n); mother = zeros(Int64, n)
+    sex = Vector{Int64}(undef, n)
     for (k, individual) in enumerate(values(pedigree))
         ind[k] = individual.ID
+        sex[k] = individual.sex
         isnothing(individual.father) || (father[k] = individual.father.ID)
         isnothing(individual.mother) || (mother[k] = individual.mother.ID)
     end
+    ind, father, mother, sex
+end
+
+function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
+             verbose::Bool = false, compute::Bool = true, device::Integer = -1)
+    ind, father, mother, _ = flatten(pedigree)
+    n = length(ind)
     plan = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve ind father mother probandIDs begin
         check(ccall((:genphi_plan_create, libgenphi), Cint,
@@ -81,6 +89,70 @@ function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(ped
     finally
         ccall((:genphi_plan_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), plan[])
     end
+end
+
+"""
+    f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
+
+Coefficients of inbreeding (`Vector{Float32}`), as `GenLib.f` (src/compute.jl:500-511), from ONE
+level sweep over the parents on the GPU plus point lookups, instead of one un-memoised pairwise
+recursion per individual.  Agrees with `GenLib.f` to the Float32-per-level rounding (~3e-8).
+"""
+function f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
+    coefficients = zeros(Float32, length(IDs))
+    pairs = [(pedigree[ID].father, pedigree[ID].mother) for ID in IDs]       # KeyError on unknown ID
+    known = findall(p -> !isnothing(p[1]) && !isnothing(p[2]), pairs)
+    isempty(known) && return coefficients
+    parents = sort(unique(vcat([pairs[k][1].ID for k in known], [pairs[k][2].ID for k in known])))
+    rows = Int64[searchsortedfirst(parents, pairs[k][1].ID) - 1 for k in known]
+    cols = Int64[searchsortedfirst(parents, pairs[k][2].ID) - 1 for k in known]
+    ind, father, mother, _ = flatten(pedigree)
+    plan = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ind father mother parents begin
+        check(ccall((:genphi_plan_create, libgenphi), Cint,
+                    (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
+                    length(ind), ind, father, mother, length(parents), parents, plan))
+    end
+    try
+        opts = Ref(GenphiOpts(Int32(device), 0, 0, 0, 0, 0))
+        check(ccall((:genphi_compute_device, libgenphi), Cint, (Ptr{Cvoid}, Ptr{GenphiOpts}, Ptr{Cvoid}),
+                    plan[], opts, C_NULL))
+        values64 = Vector{Float64}(undef, length(known))
+        GC.@preserve rows cols values64 check(ccall((:genphi_result_entries, libgenphi), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), plan[], length(known), rows, cols, values64))
+        coefficients[known] .= Float32.(values64)
+    finally
+        ccall((:genphi_plan_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), plan[])
+    end
+    coefficients
+end
+
+"""
+    branching(pedigree::GenLib.Pedigree; pro = nothing, ancestors = nothing)
+
+As `GenLib.branching` (src/extract.jl:65-186): the pedigree of the individuals on the paths
+between the selected probands and ancestors; two linear sweeps in libgenphi instead of
+recursive marking over a copied pointer graph.
+"""
+function branching(pedigree::GenLib.Pedigree; pro::Union{Vector{Int}, Nothing} = nothing,
+                   ancestors::Union{Vector{Int}, Nothing} = nothing)
+    ind, father, mother, sex = flatten(pedigree)
+    n = Ref{Int64}(0)
+    out = [Ref{Ptr{Int64}}(C_NULL) for _ in 1:4]
+    nothing_or(v) = isnothing(v) ? Ptr{Int64}(C_NULL) : (isempty(v) ? pointer(ind) : pointer(v))
+    GC.@preserve ind father mother sex pro ancestors begin
+        check(ccall((:genphi_branching, libgenphi), Cint,
+                    (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Int64, Ptr{Int64},
+                     Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}),
+                    length(ind), ind, father, mother, sex,
+                    isnothing(pro) ? 0 : length(pro), nothing_or(pro),
+                    isnothing(ancestors) ? 0 : length(ancestors), nothing_or(ancestors),
+                    n, out[1], out[2], out[3], out[4]))
+    end
+    cols = [copy(unsafe_wrap(Array, o[], Int(n[]))) for o in out]
+    foreach(o -> ccall((:genphi_free, libgenphi), Cvoid, (Ptr{Cvoid},), o[]), out)
+    # rebuild through GenLib's own constructor (already in rank order: sort = false)
+    GenLib.genealogy(GenLib.DataFrame(ind = cols[1], father = cols[2], mother = cols[3], sex = cols[4]), sort = false)
 end
 
 end # module

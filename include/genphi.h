@@ -115,6 +115,15 @@ int genphi_result_to_host(genphi_plan *plan, float *out);
  * value agrees to Float32 rounding, exactly when the sums are exact (geneaJi: 0.171875).      */
 int genphi_result_sums(genphi_plan *plan, double *sum_all, double *sum_diag, int64_t *n_rows);
 
+/* Point lookups in the resident result without moving the matrix: out[k] = Phi[rows[k], cols[k]]
+ * (0-based positions in proband order, duplicates collapsed as in genphi_plan_create; rows must
+ * lie in the resident row range).  This is what gen.f(pedigree, IDs) (src/compute.jl:500-511)
+ * needs: the inbreeding coefficient of x is the kinship of its parents, one entry of the sweep
+ * over the parents instead of the reference's un-memoised pairwise recursion (:66-95).  Values
+ * are the Float32 entries widened to Float64.                                                  */
+int genphi_result_entries(genphi_plan *plan, int64_t n, const int64_t *rows, const int64_t *cols,
+                          double *out);
+
 /* Convenience = genphi_compute_device + genphi_result_to_host: what the Julia shim's
  * phi(...; compute=true) calls.  out: N x N Float32, caller-owned.                           */
 int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,
@@ -129,6 +138,19 @@ int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,
 int genphi_genealogy_read(const char *path, int32_t sort, int64_t *n, int64_t **ind, int64_t **father,
                           int64_t **mother, int64_t **sex_out);
 void genphi_free(void *ptr);
+
+/* gen.branching(pedigree; pro, ancestors) (src/extract.jl:65-186), the pruning step before the
+ * path: keeps the individuals on the paths between the selected probands and ancestors.
+ * Input: the pedigree in rank order (as for genphi_plan_create) plus sex (may be NULL -> 0).
+ * pro == NULL / ancestors == NULL mean "not given" (Julia `nothing`): with only pro, the
+ * probands and all their ancestors are kept; with only ancestors, they and all their
+ * descendants (parents outside the set become unknown); with both, the intersection (parents
+ * outside it become unknown); with neither, nobody.  Output arrays are in the input's rank
+ * order, allocated by the library (genphi_free each).  Unknown ID -> GENPHI_ERR_UNKNOWN_ID.   */
+int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                     const int64_t *sex, int64_t n_pro, const int64_t *pro, int64_t n_anc,
+                     const int64_t *ancestors, int64_t *n_out, int64_t **ind_out, int64_t **father_out,
+                     int64_t **mother_out, int64_t **sex_out);
 
 /* Frees host and device memory of the plan (NULL is allowed). */
 void genphi_plan_destroy(genphi_plan *plan);

@@ -183,6 +183,57 @@ class Pedigree:
         return out
 
 
+    def branching(self, pro=None, ancestors=None):
+        """gen.branching (src/extract.jl:65-186), restated as written there: build the
+        children lists (:73-92), mark the ancestors of every proband (:32-42, :93-99) and the
+        descendants of every ancestor (:49-58, :100-106) by graph walks, then emit in pedigree
+        order the individuals selected by the three cases (:108-184), cutting parents that
+        fall outside the kept set.  Pure Python (small inputs).  Returns (ind, father, mother)."""
+        n = self.n
+        pos = {int(i): k for k, i in enumerate(self.ind)}
+        fa = [pos[int(x)] if x else -1 for x in self.father]
+        mo = [pos[int(x)] if x else -1 for x in self.mother]
+        children = [[] for _ in range(n)]
+        for k in range(n):
+            if fa[k] >= 0:
+                children[fa[k]].append(k)
+            if mo[k] >= 0:
+                children[mo[k]].append(k)
+        is_anc, is_desc = [False] * n, [False] * n
+
+        def walk(start, flags, nxt):                       # the reference recurses; same marks
+            stack = [start]
+            while stack:
+                x = stack.pop()
+                if not flags[x]:
+                    flags[x] = True
+                    stack.extend(nxt(x))
+
+        if pro is not None:
+            for i in pro:
+                if int(i) not in pos:
+                    raise OracleError(int(i))
+                walk(pos[int(i)], is_anc, lambda x: [q for q in (fa[x], mo[x]) if q >= 0])
+        if ancestors is not None:
+            for i in ancestors:
+                if int(i) not in pos:
+                    raise OracleError(int(i))
+                walk(pos[int(i)], is_desc, lambda x: children[x])
+        if pro is not None and ancestors is not None:
+            keep = [a and d for a, d in zip(is_anc, is_desc)]
+        elif pro is not None:
+            keep = is_anc
+        elif ancestors is not None:
+            keep = is_desc
+        else:
+            keep = [False] * n
+        out = [(int(self.ind[k]),
+                int(self.father[k]) if fa[k] >= 0 and keep[fa[k]] else 0,
+                int(self.mother[k]) if mo[k] >= 0 and keep[mo[k]] else 0) for k in range(n) if keep[k]]
+        a = np.array(out, dtype=np.int64).reshape(-1, 3)
+        return a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
+
+
 def phi_mean(phi):
     phi = np.ascontiguousarray(phi, dtype=np.float32)
     return float(lib().oracle_phi_mean(phi.ctypes.data_as(_F32P), phi.shape[0]))

@@ -183,6 +183,47 @@ def test_phi_mean_on_device(gen, oracle):
     pl.close()
 
 
+def test_inbreeding_f_from_the_sweep(gen, oracle):
+    """gen.f(pedigree, IDs) (src/compute.jl:500-511) from one level sweep
+    over the parents + point lookups (genphi_result_entries) instead of the exponential
+    pairwise recursion."""
+    ped = gen.genealogy(gen.geneaJi)
+    assert gen.f(ped, [1]).tolist() == [GOLD["geneaJi"]["f_1"]]            # test/runtests.jl:47, exact
+    assert gen.f(ped, [17]).tolist() == [GOLD["geneaJi"]["f_17"]]          # :48
+    assert gen.f(ped, [1]).dtype == np.float32
+    op = oracle.Pedigree.from_file(gen.geneaJi)
+    assert np.array_equal(gen.f(ped, ped.ind), op.f(ped.ind))              # every individual, exact (dyadic)
+    with pytest.raises(KeyError):
+        gen.f(ped, [424242])
+    # genea140: bit-equal to the oracle's level sweep over the same parents, and within the
+    # Float32-per-level rounding of the exact pairwise recursion (SURVEY fact 5: <= ~3e-8)
+    ped = gen.genealogy(gen.genea140)
+    op = oracle.Pedigree.from_file(gen.genea140)
+    ids = gen.pro(ped)
+    got = gen.f(ped, ids)
+    pos = ped.positions(ids)
+    fa, mo = ped.father[pos], ped.mother[pos]
+    both = (fa != 0) & (mo != 0)
+    parents = np.unique(np.concatenate([fa[both], mo[both]]))
+    sweep = op.phi(parents)
+    want = np.zeros(len(ids), dtype=np.float32)
+    want[both] = sweep[np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both])]
+    assert np.array_equal(got, want)
+    assert np.count_nonzero(got) > 0
+    exact = op.f(ids[:40])
+    assert np.max(np.abs(got[:40].astype(np.float64) - exact.astype(np.float64))) <= 4e-8
+    # point lookups: any entry of a resident (sharded) result
+    pl = gen.plan(ped)
+    full = pl.compute()
+    r = np.array([0, 5, 139, 77]); c = np.array([139, 5, 0, 12])
+    assert np.array_equal(pl.result_entries(r, c), full[r, c].astype(np.float64))
+    pl.compute_device(rows=(60, 140))
+    assert np.array_equal(pl.result_entries([60, 139], [3, 139]), full[[60, 139], [3, 139]].astype(np.float64))
+    with pytest.raises(ValueError):
+        pl.result_entries([10], [3])                                       # row not resident
+    pl.close()
+
+
 def _random_pedigree(rng, n, p_founder, p_one_parent, p_selfing, max_back):
     """Arbitrary pedigree in id order (parents have smaller ids): overlapping generations,
     one-parent individuals, founders anywhere, occasional selfing, sex not enforced."""

@@ -177,3 +177,39 @@ def test_native_loader_matches_oracle_rank_order(gen, oracle, tmp_path):
     bad.write_text("ind\tfather\tmother\tsex\n1\t2\t0\t1\n2\t1\t0\t1\n")
     with pytest.raises(ValueError):
         _capi.genealogy_read(str(bad))                 # cycle
+
+
+def test_branching_matches_reference_checks_and_oracle(gen, oracle):
+    """gen.branching (src/extract.jl:65-186) through the C-ABI (genphi_branching): the
+    reference's own three checks (test/runtests.jl:69-74), then array equality with the
+    oracle's restatement on genea140 and on a synthetic pedigree, all three argument cases."""
+    ped = gen.genealogy(gen.geneaJi)
+    assert gen.founder(gen.branching(ped, pro=[1])).tolist() == [17, 19, 20, 25, 26]
+    assert gen.pro(gen.branching(ped, ancestors=[13])).tolist() == [1, 2]
+    assert gen.branching(ped, pro=[1], ancestors=[13]).ind.tolist() == [13, 8, 4, 1]
+    assert len(gen.branching(ped)) == 0
+    with pytest.raises(KeyError):
+        gen.branching(ped, pro=[12345])
+    with pytest.raises(KeyError):
+        gen.branching(ped, ancestors=[12345])
+
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(3000, 300, 8, skip_permille=60)
+    cases = [(gen.genealogy(gen.genea140), oracle.Pedigree.from_file(gen.genea140)),
+             (gen.Pedigree(ind, fa, mo, sex), oracle.Pedigree(ind, fa, mo, sort=False))]
+    rng = np.random.default_rng(11)
+    for gp, op in cases:
+        pr = rng.choice(gen.pro(gp), size=7, replace=False)
+        an = rng.choice(gen.founder(gp), size=5, replace=False)
+        for kw in ({"pro": pr}, {"ancestors": an}, {"pro": pr, "ancestors": an}, {"pro": np.zeros(0, np.int64)}):
+            got = gen.branching(gp, **kw)
+            want = op.branching(**kw)
+            assert np.array_equal(got.ind, want[0]) and np.array_equal(got.father, want[1]) \
+                and np.array_equal(got.mother, want[2]), kw.keys()
+            # sex travels with the individual
+            assert np.array_equal(got.sex, gp.sex[gp.positions(got.ind)])
+        # pruning to the probands' ancestors does not change the levelisation gen.phi does
+        sub = gen.branching(gp, pro=pr)
+        a, b = gen.plan(gp, np.sort(pr)), gen.plan(sub, np.sort(pr))
+        assert a.levels() == b.levels()
+        a.close(); b.close()

@@ -27,6 +27,18 @@ def test_geneaJi_reference_pinned(oracle):
     assert sizes == g["cut_sizes_survey"] and both == g["both_survey"]
 
 
+def test_geneaJi_branching_reference_pinned(oracle):
+    """The reference's own checks of gen.branching (test/runtests.jl:69-74), on the oracle."""
+    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "geneaJi.csv"))
+    iso = oracle.Pedigree(*ped.branching(pro=[1]), sort=False)
+    assert iso.founder().tolist() == [17, 19, 20, 25, 26]                  # :70
+    iso = oracle.Pedigree(*ped.branching(ancestors=[13]), sort=False)
+    assert iso.pro().tolist() == [1, 2]                                    # :72
+    ind, _, _ = ped.branching(pro=[1], ancestors=[13])
+    assert ind.tolist() == [13, 8, 4, 1]                                   # :74 (pedigree order)
+    assert len(ped.branching()[0]) == 0                                    # neither given: empty
+
+
 def test_genea140_survey_derived(oracle):
     g = GOLD["genea140_survey_derived"]
     ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "genea140.csv"))
