@@ -258,6 +258,19 @@ __device__ __forceinline__ void store_row4(float *row, unsigned row_bytes, unsig
 // a single store_pre site and a single load_pre site, so that the staging registers are
 // allocated once -- register pressure is the limiter here, and a spill is fatal to the
 // pipeline (scratch reloads wait on vmcnt(0), i.e. on the prefetch in flight).
+// Profiling aid (compile with -DGENPHI_WG_TIMES=1): per workgroup (start, end) wall-clock ticks
+// and items started, of the LAST level_split_kernel launch; read with genphi_debug_wg_times.
+#ifndef GENPHI_WG_TIMES
+#define GENPHI_WG_TIMES 0
+#endif
+#if GENPHI_WG_TIMES
+__device__ unsigned long long g_wg_times[1024][3];
+__device__ unsigned long long g_wg_phase[1024][8];   // summed ticks per stage phase (thread 0), [6] = stages, [7] = B stages
+#define GENPHI_PHASE(k) do { const unsigned long long t_ = wall_clock64(); ph[k] += t_ - t_ph; t_ph = t_; } while (0)
+#else
+#define GENPHI_PHASE(k) do { } while (0)
+#endif
+
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
 __global__ void __launch_bounds__(NTHREADS)
 level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, int *queue)
@@ -271,24 +284,38 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     // by the host): items cost 1..5 stages, a static split leaves a tail.  Thread 0 draws the
     // item after next during stage A of each item and hands it over through an LDS slot, so
     // the draw's latency never sits in front of a prefetch.
+    // When its own slice is drained a workgroup goes on with the slices of the other XCDs
+    // (same counters): the XCDs do not run at the same speed (the last one finished 8 % after
+    // the first on the final level of cfg4), and a slice boundary is only a locality hint.
     const int n_items = p.n_groups * p.n_chunks;
     const int xcd = blockIdx.x & 7;
     const int q = n_items >> 3, rem = n_items & 7;
-    const int begin = xcd * q + min(xcd, rem);
-    const int len = q + (xcd < rem ? 1 : 0);
+    auto draw = [&]() -> int {                            // global item index, or n_items when all is drawn
+#pragma unroll 1
+        for (int t = 0; t < 8; ++t) {
+            const int x = (xcd + t) & 7;
+            const int l = atomicAdd(&queue[x], 1);
+            if (l < q + (x < rem ? 1 : 0)) return x * q + min(x, rem) + l;
+        }
+        return n_items;
+    };
     if (p.zero_row && blockIdx.x == 0) {                  // the all-zero "none" row of this level
         float *zr = p.out + (long long)p.n * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
     int *slot = reinterpret_cast<int *>(lds + p.slot_off);
     if (threadIdx.x == 0) {
-        slot[0] = atomicAdd(&queue[xcd], 1);
-        slot[1] = atomicAdd(&queue[xcd], 1);
+        slot[0] = draw();
+        slot[1] = draw();
     }
     __syncthreads();
-    int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);  // this item / the next one (slice-local)
+    int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);  // this item / the next one (global item indices)
     int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
-    if (cur_l >= len) return;
+#if GENPHI_WG_TIMES
+    const unsigned long long t_start = wall_clock64();
+    if (threadIdx.x == 0) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; }
+#endif
+    if (cur_l >= n_items) return;
     int kc = 0;                                           // items this workgroup has started
     unsigned tl = threadIdx.x;                            // re-materialised per stage (see asm below)
 
@@ -310,13 +337,13 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     constexpr int NQ = CPT / 4;
 
     // ---- stage state (all wave-uniform) ----
-    int it = begin + cur_l;                               // current item
+    int it = cur_l;                                       // current item
     int g = it / p.n_chunks;
     int chunk = it - g * p.n_chunks;
     int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
     int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
-    bool have_next = nxt_l < len;
+    bool have_next = nxt_l < n_items;
     unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
     // columns [n, ld) (the "none" column and the pitch padding) are written as part of the
     // last chunk: their padded index words point at the zero column, so they come out as 0
@@ -325,6 +352,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 #pragma unroll
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
 
+#if GENPHI_WG_TIMES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ph = wall_clock64();
+#endif
     for (;;) {
         // keep the per-column address arithmetic inside the loop: hoisted out it costs VGPRs
         // per column.  z0 is a zero the compiler cannot see through: XOR-ing the loop-carried
@@ -334,24 +364,47 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         asm volatile("" : "+v"(tl));
         __builtin_assume(tl < NT);
 
-        __syncthreads();                                // previous gathers are done with the buffer
-#pragma unroll
-        for (int k_ = 0; k_ < STG; ++k_)
-            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
-        __syncthreads();
-
-        // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
-        //      order, so the gathers below only wait for these) and the next stage's source ----
+        // ---- part 0: the stage's scalar descriptors, issued BEFORE the barriers so that their
+        //      latency (scalar cache / L2 round trips, ~0.8 us per stage when they sat in front
+        //      of the prefetch) overlaps with the wait for the other waves and the LDS writes ----
         int4 dsc = make_int4(0, 0, 0, 0);
         int nextB;                                      // B source of the next child, or n_prev
         if (stage_is_a) {
+            nextB = desc[wb].z;
+        } else {
+            dsc = desc[w];
+            nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
+        }
+        GENPHI_PHASE(5);                                // stage bookkeeping
+        __syncthreads();                                // previous gathers are done with the buffer
+        GENPHI_PHASE(0);
+        if (stage_is_a && kc > 0) {
+            // the item after next was drawn by thread 0 during the previous item's stage A; the
+            // barrier above orders that LDS write before this read
+            nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
+            have_next = nxt_l < n_items;
+        }
+        // next stage: B row of the next child that has one, else row A of the next item
+        // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
+        const int next_item = nxt_l;
+        const int gn = have_next ? next_item / p.n_chunks : g;
+        const int nextAi = grp[gn].y;
+#pragma unroll
+        for (int k_ = 0; k_ < STG; ++k_)
+            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
+        GENPHI_PHASE(1);                                // wait for the prefetched row + LDS writes issued
+        __syncthreads();
+        GENPHI_PHASE(2);
+#if GENPHI_WG_TIMES
+        ph[6] += 1; ph[7] += stage_is_a ? 0 : 1;
+#endif
+
+        // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
+        //      order, so the gathers below only wait for these) and the next stage's source ----
+        if (stage_is_a) {
             // the item after next: drawn now by thread 0 (oldest memory op of the stage, so
             // waiting for it never waits for the prefetch), read by everyone one item later
-            if (kc > 0) {
-                nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
-                have_next = nxt_l < len;
-            }
-            if (threadIdx.x == 0) slot[kc & 1] = atomicAdd(&queue[xcd], 1);
+            if (threadIdx.x == 0) slot[kc & 1] = draw();
             ++kc;
             if (!POS_ORD) {
                 // rank words first, alone: they are folded into the per-child masks and dead
@@ -382,22 +435,14 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 const u4_t v = ld_off<u4_t>(p.pk, (cb + q * 4 * NT + tl * 4) * 4u);
                 pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
             }
-            nextB = desc[wb].z;
-        } else {
-            dsc = desc[w];
-            nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
         }
-        // next stage: B row of the next child that has one, else row A of the next item
-        // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
-        const int next_item = begin + nxt_l;
-        const int gn = have_next ? next_item / p.n_chunks : g;
-        const int nextAi = grp[gn].y;
         {
             const float *src = p.psi + (long long)(nextB != p.n_prev ? nextB : nextAi) * p.ld_prev;
 #pragma unroll
             for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
         }
 
+        GENPHI_PHASE(3);                                // index loads + prefetch issue
         // ---- part 2: gathers from the staged row ----
         int wfin_b, wfin_e;                             // children without a B source to finish now
         if (stage_is_a) {
@@ -466,6 +511,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             }
         }
 
+        GENPHI_PHASE(4);                                // gathers, combine, row stores
         // ---- advance the stage state ----
         if (nextB != p.n_prev) {                        // next stage: B row of the next child
             w = stage_is_a ? wb : w + 1;
@@ -482,6 +528,12 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
         }
     }
+#if GENPHI_WG_TIMES
+    if (threadIdx.x == 0) {
+        g_wg_times[blockIdx.x][1] = wall_clock64(); g_wg_times[blockIdx.x][2] = kc;
+        for (int k = 0; k < 8; ++k) g_wg_phase[blockIdx.x][k] = ph[k];
+    }
+#endif
 }
 
 // ---- HALF: fallback for cuts too wide for one row in LDS (> ~40k members) --------------------
@@ -1286,6 +1338,17 @@ int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const 
     if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_entries: ") + hipGetErrorString(e));
     return GENPHI_OK;
 }
+
+#if GENPHI_WG_TIMES
+int genphi_debug_wg_times(unsigned long long *out /* [1024][3] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(unsigned long long) * 1024 * 3) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
+}
+int genphi_debug_wg_phases(unsigned long long *out /* [1024][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
+}
+#endif
 
 int genphi_compute_f32(genphi_plan *p, float *out, const genphi_opts *opts, genphi_stats *stats)
 {

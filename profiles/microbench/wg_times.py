@@ -1,0 +1,37 @@
+"""Per-workgroup busy time of the last level step (needs lib/libgenphi_dbg.so built with
+-DGENPHI_WG_TIMES=1).  usage: python wg_times.py N_PRO"""
+import os, sys, ctypes as C
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import numpy as np
+import genlib_jl_amd as gen
+from genlib_jl_amd import synth, _capi
+_capi.LIB_PATH = os.path.join(root, "genlib.jl_amd", "lib", "libgenphi_dbg.so")
+n_pro = int(sys.argv[1])
+ind, fa, mo, sex, pro = synth.random_mating(31034 * 3 + n_pro, n_pro, 4)
+ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+pl = gen.plan(ped, pro)
+for _ in range(3):
+    st = pl.compute_device(timing=True)
+buf = np.zeros((1024, 3), dtype=np.uint64)
+L = _capi.lib()
+L.genphi_debug_wg_times.argtypes = [C.c_void_p]
+assert L.genphi_debug_wg_times(buf.ctypes.data) == 0
+t = buf[:256].astype(np.float64)
+t0 = t[:, 0].min()
+start, end, items = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]     # wall_clock64: 100 MHz -> us
+print("final level ms", st.level_ms[st.n_steps - 1], "teams", os.environ.get("GENPHI_TEAMS"))
+for x in range(8):
+    m = np.arange(256) % 8 == x
+    print(f"xcd {x}: start {start[m].min():8.1f}..{start[m].max():8.1f} us  end {end[m].min():9.1f}..{end[m].max():9.1f} us  items/WG {items[m].min():.0f}..{items[m].max():.0f}  total {items[m].sum():.0f}")
+ph = np.zeros((1024, 8), dtype=np.uint64)
+L.genphi_debug_wg_phases.argtypes = [C.c_void_p]
+assert L.genphi_debug_wg_phases(ph.ctypes.data) == 0
+ph = ph[:256].astype(np.float64)
+st_n = ph[:, 6].sum()
+names = ["barrier 1 (others still gathering)", "wait prefetched row + LDS writes", "barrier 2", "index loads + prefetch issue",
+         "gathers + combine + stores", "bookkeeping"]
+print(f"stages {st_n:.0f} (B stages {ph[:, 7].sum():.0f}); mean us per stage by phase (thread 0 of each workgroup):")
+for k, nm in enumerate(names):
+    print(f"  {nm:40s} {ph[:, k].sum() / st_n / 100.0:7.3f}")
+print(f"  {'total':40s} {ph[:, :6].sum() / st_n / 100.0:7.3f}")
