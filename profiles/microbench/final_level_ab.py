@@ -1,5 +1,8 @@
-"""A/B of the last level step only: few generations, n_pro probands, with/without GENPHI_TEAMS.
-usage: python final_level_ab.py N_PRO [N_PRO ...]  (run on the GPU box)"""
+"""Time of the last level step only (4 generations, N_PRO probands) under an environment switch.
+usage: python final_level_ab.py N_PRO [N_PRO ...]  (run on the GPU box).  Was used for the
+GENPHI_TEAMS experiment (static chunk teams, DESIGN.md 5: removed again); VARIANTS is the
+list of values tried for ENV_NAME."""
+ENV_NAME, VARIANTS = "GENPHI_MAX_CPT", ("28", "16")
 import os, sys, subprocess, json
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -17,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print(json.dumps({"n_pro": n_pro, "cuts": pl.levels()[0], "final_ms": best, "sums": pl.result_sums()[:2]}))
 else:
     for n in sys.argv[1:]:
-        for t in ("0", "1", "2"):
-            env = dict(os.environ, GENPHI_TEAMS=t)
+        for t in VARIANTS:
+            env = dict(os.environ, **{ENV_NAME: t})
             out = subprocess.run([sys.executable, __file__, "--child", n], env=env, capture_output=True, text=True)
-            print("teams=" + t, out.stdout.strip() or out.stderr[-400:])
+            print(ENV_NAME + "=" + t, out.stdout.strip() or out.stderr[-400:])

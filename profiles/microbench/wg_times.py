@@ -1,5 +1,6 @@
-"""Per-workgroup busy time of the last level step (needs lib/libgenphi_dbg.so built with
--DGENPHI_WG_TIMES=1).  usage: python wg_times.py N_PRO"""
+"""Per-workgroup busy time and per-phase stage timing of the last level step.  Needs
+genlib.jl_amd/lib/libgenphi_dbg.so = the three csrc files built with the flags of
+__graft_entry__.build() plus -DGENPHI_WG_TIMES=1.  usage: python wg_times.py N_PRO"""
 import os, sys, ctypes as C
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -20,7 +21,7 @@ assert L.genphi_debug_wg_times(buf.ctypes.data) == 0
 t = buf[:256].astype(np.float64)
 t0 = t[:, 0].min()
 start, end, items = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]     # wall_clock64: 100 MHz -> us
-print("final level ms", st.level_ms[st.n_steps - 1], "teams", os.environ.get("GENPHI_TEAMS"))
+print("final level ms", st.level_ms[st.n_steps - 1])
 for x in range(8):
     m = np.arange(256) % 8 == x
     print(f"xcd {x}: start {start[m].min():8.1f}..{start[m].max():8.1f} us  end {end[m].min():9.1f}..{end[m].max():9.1f} us  items/WG {items[m].min():.0f}..{items[m].max():.0f}  total {items[m].sum():.0f}")
