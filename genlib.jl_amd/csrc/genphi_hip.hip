@@ -99,6 +99,7 @@ struct LevelArgs {
     int n_chunks;            // SPLIT: column chunks per row (work item = sibling group x chunk)
     int n_groups;            // SPLIT: sibling groups (runs of equal A source in the work list)
     int slot_off;            // SPLIT: float offset in LDS of the two work-queue hand-over slots
+    int dbg;                 // GENPHI_WG_TIMES builds: record this launch's workgroup timing
     int zero_row;            // !=0: this launch also zeroes the "none" row n of `out` (intermediate levels)
 };
 
@@ -313,7 +314,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
 #if GENPHI_WG_TIMES
     const unsigned long long t_start = wall_clock64();
-    if (threadIdx.x == 0) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; }
+    if (threadIdx.x == 0 && p.dbg) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; }
 #endif
     if (cur_l >= n_items) return;
     int kc = 0;                                           // items this workgroup has started
@@ -529,7 +530,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         }
     }
 #if GENPHI_WG_TIMES
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && p.dbg) {
         g_wg_times[blockIdx.x][1] = wall_clock64(); g_wg_times[blockIdx.x][2] = kc;
         for (int k = 0; k < 8; ++k) g_wg_phase[blockIdx.x][k] = ph[k];
     }
@@ -977,6 +978,10 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
     a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
     a.segs = d.segs; a.b_rel = d.b_rel; a.n_segs = static_cast<int>(s.segs.size());
     a.lds_row = 0; a.chunk_cols = 0;
+    {   // which level step GENPHI_WG_TIMES builds record: GENPHI_DBG_STEP (default: the last one)
+        const char *e = std::getenv("GENPHI_DBG_STEP");
+        a.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step ? 1 : 0;
+    }
     a.zero_row = (out_rows == nullptr && kernel != 1 && s.mode != genphi::kModeHalf) ? 1 : 0;
     if (n_rows <= 0) return GENPHI_OK;
     const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);

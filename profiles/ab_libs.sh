@@ -1,0 +1,17 @@
+#!/bin/bash
+# Same-box A/B of two builds of libgenphi.so (boxes differ by several per cent, so only numbers
+# from ONE gpurun call are comparable).  usage: ab_libs.sh before.so after.so [workload]
+A=$1; B=$2; WL=${3:-cfg4}
+cp genlib.jl_amd/lib/libgenphi.so /tmp/keep.so
+for rep in 1 2 3; do
+  for v in "$A" "$B"; do
+    cp "$v" genlib.jl_amd/lib/libgenphi.so
+    timeout -k 10 200 python bench.py --workload "$WL" --no-cpu-baseline > /tmp/ab.json 2> /tmp/ab.err || { echo "fail $v"; tail -3 /tmp/ab.err; }
+    python - "$v" <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab.json")); l = d["config"]["level_ms"]
+print(sys.argv[1].split("/")[-1], round(d["ms_per_step"], 2), "upper", round(sum(l[1:24]) / 23, 4) if len(l) > 25 else "", "final", round(l[-1], 3))
+PY
+  done
+done
+cp /tmp/keep.so genlib.jl_amd/lib/libgenphi.so

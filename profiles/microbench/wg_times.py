@@ -9,7 +9,8 @@ import genlib_jl_amd as gen
 from genlib_jl_amd import synth, _capi
 _capi.LIB_PATH = os.path.join(root, "genlib.jl_amd", "lib", "libgenphi_dbg.so")
 n_pro = int(sys.argv[1])
-ind, fa, mo, sex, pro = synth.random_mating(31034 * 3 + n_pro, n_pro, 4)
+n_gen = int(sys.argv[2]) if len(sys.argv) > 2 else 4          # GENPHI_DBG_STEP=k picks an earlier level step
+ind, fa, mo, sex, pro = synth.random_mating(31034 * (n_gen - 1) + n_pro, n_pro, n_gen)
 ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
 pl = gen.plan(ped, pro)
 for _ in range(3):
@@ -21,7 +22,8 @@ assert L.genphi_debug_wg_times(buf.ctypes.data) == 0
 t = buf[:256].astype(np.float64)
 t0 = t[:, 0].min()
 start, end, items = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]     # wall_clock64: 100 MHz -> us
-print("final level ms", st.level_ms[st.n_steps - 1])
+k_ = int(os.environ.get("GENPHI_DBG_STEP", st.n_steps - 1))
+print("cuts", pl.levels()[0], "step", k_, "ms", st.level_ms[k_])
 for x in range(8):
     m = np.arange(256) % 8 == x
     print(f"xcd {x}: start {start[m].min():8.1f}..{start[m].max():8.1f} us  end {end[m].min():9.1f}..{end[m].max():9.1f} us  items/WG {items[m].min():.0f}..{items[m].max():.0f}  total {items[m].sum():.0f}")
