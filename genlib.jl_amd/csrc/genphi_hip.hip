@@ -22,6 +22,9 @@
 //   level_half_kernel   fallback above ~40k members: only a window of the B-side (mother)
 //       columns is staged; the A-side (father) terms are read straight from HBM/L2 -- the
 //       planner stores the columns sorted by A inside each window bucket.
+//   levels_small_kernel a RUN of consecutive steps with cuts <= 128 members in one persistent
+//       launch: both level matrices live in LDS, one barrier per level (deep small pedigrees
+//       are launch-bound otherwise).
 //   level_naive_kernel             one thread per entry, four global gathers (reference
 //       kernel for A/B comparisons; opts.kernel = 1).
 //   colperm_kernel                 proband-order delivery of a final level computed in
@@ -604,6 +607,69 @@ __global__ void level_naive_kernel(const LevelArgs p)
     p.out[orow * p.ld + j] = v;
 }
 
+// ---- SMALL: a run of consecutive level steps whose cuts have <= kSmallMax members, fused -----
+// Deep small pedigrees (hundreds of generations of a few dozen individuals: breeding lines,
+// cfg5) are launch-bound: a level is a few microseconds of work.  One workgroup keeps BOTH
+// level matrices of such a run in LDS and walks the steps back to back: no launches, no HBM
+// round trips, one barrier per level.  Same per-entry arithmetic as level_naive_kernel
+// (src/compute.jl:105-158 on Float32 storage, one rounding per entry per level).
+constexpr int kSmallMax = 128;                // members per cut
+constexpr int kSmallPitch = kSmallMax + 4;    // row pitch in LDS; column / row n ("none") stay zero
+struct SmallStep {
+    const int *srcA, *srcB, *ord;
+    int n_prev, n;
+};
+
+__global__ void __launch_bounds__(1024)
+levels_small_kernel(const SmallStep *__restrict__ steps, int n_run, const float *__restrict__ in, long long ld_in,
+                    int in_is_half_identity, float *__restrict__ out, long long ld_out)
+{
+    extern __shared__ float lds[];
+    constexpr int P = kSmallPitch;
+    float *cur = lds, *nxt = lds + P * P;
+    int *sa = reinterpret_cast<int *>(lds + 2 * P * P), *sb = sa + kSmallMax, *so = sb + kSmallMax;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    // the run's input matrix, with its zero "none" row and column (index n_prev)
+    const int n0 = steps[0].n_prev;
+    for (int idx = tid; idx < (n0 + 1) * (n0 + 1); idx += nt) {
+        const int i = idx / (n0 + 1), j = idx - i * (n0 + 1);
+        float v = 0.f;
+        if (i < n0 && j < n0) v = in_is_half_identity ? (i == j ? 0.5f : 0.f) : in[(long long)i * ld_in + j];
+        cur[i * P + j] = v;
+    }
+    for (int s = 0; s < n_run; ++s) {
+        const SmallStep st = steps[s];
+        for (int k = tid; k < st.n; k += nt) { sa[k] = st.srcA[k]; sb[k] = st.srcB[k]; so[k] = st.ord[k]; }
+        __syncthreads();                                        // `cur` and the index arrays are complete
+        const int n = st.n, n1 = n + 1;
+        for (int idx = tid; idx < n1 * n1; idx += nt) {
+            const int i = idx / n1, j = idx - i * n1;
+            float v = 0.f;                                      // row / column n: the next level's "none"
+            if (i < n && j < n) {
+                const int Ai = sa[i], Bi = sb[i], oi = so[i];
+                if (j == i && oi < 0) {
+                    v = static_cast<float>(0.5 + 0.5 * static_cast<double>(cur[Ai * P + Bi]));
+                } else {
+                    const int Aj = sa[j], Bj = sb[j], oj = so[j];
+                    const double sc = (oi < 0 ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
+                    v = combine(cur[Ai * P + Aj], cur[Ai * P + Bj], cur[Bi * P + Aj], cur[Bi * P + Bj],
+                                (oi & kOrdMask) > (oj & kOrdMask), sc);
+                }
+            }
+            nxt[i * P + j] = v;
+        }
+        __syncthreads();                                        // everyone is done reading `cur` / sa..so
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    // the run's result in the regular padded layout (rows 0..n incl. the zero row, whole pitch)
+    const int n = steps[n_run - 1].n;
+    for (long long idx = tid; idx < (long long)(n + 1) * ld_out; idx += nt) {
+        const int i = static_cast<int>(idx / ld_out), j = static_cast<int>(idx - (long long)i * ld_out);
+        out[idx] = (j <= n) ? cur[i * P + j] : 0.f;
+    }
+}
+
 // Psi_1 = 1/2 I over the top founders (src/compute.jl:271-274); buffer pre-zeroed.
 __global__ void half_identity_kernel(float *m, long long ld, int n, const int *out_rows, int n_rows, int row_begin)
 {
@@ -721,6 +787,7 @@ struct genphi_plan {
     int *d_final_perm = nullptr;
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
     int *d_queues = nullptr;        // 8 work-queue counters per level step
+    SmallStep *d_small = nullptr;   // one entry per level step (levels_small_kernel)
     hipGraphExec_t graph_exec = nullptr;   // captured sweep (see genphi_compute_device)
     long long graph_key[4] = {0, 0, 0, 0}, eager_key[4] = {0, 0, 0, 0};
     bool eager_valid = false;
@@ -750,6 +817,7 @@ static void free_device(genphi_plan *p)
     (void)hipFree(p->d_shard_out_rows);
     (void)hipFree(p->d_shard_desc);
     (void)hipFree(p->d_queues);
+    (void)hipFree(p->d_small);
     (void)hipFree(p->d_shard_grp);
     (void)hipFree(p->buf[0]);
     (void)hipFree(p->buf[1]);
@@ -888,6 +956,15 @@ static int upload_plan(genphi_plan *p, int device)
     HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
 
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_queues), (pl.steps.size() + 1) * 8 * sizeof(int)));
+    {
+        std::vector<SmallStep> sm(pl.steps.size() + 1);
+        for (size_t k = 0; k < pl.steps.size(); ++k)
+            sm[k] = SmallStep{p->dsteps[k].srcA, p->dsteps[k].srcB, p->dsteps[k].ord,
+                              static_cast<int>(pl.steps[k].n_prev), static_cast<int>(pl.steps[k].n)};
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_small), sm.size() * sizeof(SmallStep)));
+        HIP_TRY(hipMemcpyAsync(p->d_small, sm.data(), sm.size() * sizeof(SmallStep), hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
     for (int c = 0; c + 1 < pl.n_levels; ++c)
@@ -1135,6 +1212,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
 
     // ---- the sweep: every launch of one gen.phi, in stream order ------------------------------
+    const bool small_off = std::getenv("GENPHI_NO_SMALL") != nullptr;            // test hook: per-level launches only
+    std::vector<int> ev_after(std::max(n_steps, 1));                             // event recorded after step k (timing)
+    for (int k = 0; k < static_cast<int>(ev_after.size()); ++k) ev_after[k] = k + 1;
     auto enqueue = [&]() -> int {
         HIP_TRY(hipMemsetAsync(p->d_queues, 0, (pl.steps.size() + 1) * 8 * sizeof(int), p->stream));
         if (n_steps == 0) {
@@ -1156,6 +1236,27 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 const LevelStep &st = pl.steps[s];
                 const float *psi = p->buf[s & 1];
                 const bool last = s == n_steps - 1;
+                // a run of >= 2 small intermediate steps goes through ONE launch (levels_small_kernel)
+                if (kernel == 0 && !small_off) {
+                    int e = s;
+                    while (e < n_steps - 1 && pl.steps[e].n_prev <= kSmallMax && pl.steps[e].n <= kSmallMax) ++e;
+                    if (e - s >= 2) {
+                        const size_t lds = (2 * kSmallPitch * kSmallPitch + 3 * kSmallMax) * sizeof(float);
+                        HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));
+                        hipLaunchKernelGGL(levels_small_kernel, dim3(1), dim3(1024), lds, p->stream, p->d_small + s, e - s,
+                                           psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[e & 1],
+                                           static_cast<long long>(pl.ld[e]));
+                        HIP_TRY(hipGetLastError());
+                        // per-level timing: ONE event for the run, booked on its first step (an event
+                        // record costs more than a fused level)
+                        if (timing) {
+                            HIP_TRY(hipEventRecord(p->events[e], p->stream));
+                            for (int k = s; k < e; ++k) ev_after[k] = e;
+                        }
+                        s = e - 1;
+                        continue;
+                    }
+                }
                 if (!last) {
                     float *out = p->buf[(s + 1) & 1];
                     rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
@@ -1221,7 +1322,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         HIP_TRY(hipEventElapsedTime(&ms, p->events[0], p->events[ne]));
         stats->total_ms = ms;
         for (int s = 0; s < ne; ++s) {
-            HIP_TRY(hipEventElapsedTime(&ms, p->events[s], p->events[s + 1]));
+            const int e0 = s == 0 ? 0 : ev_after[s - 1], e1 = ev_after[s];
+            ms = 0.f;
+            if (e1 != e0) HIP_TRY(hipEventElapsedTime(&ms, p->events[e0], p->events[e1]));
             stats->level_ms[s] = ms;
         }
         stats->final_ms = stats->level_ms[ne - 1];

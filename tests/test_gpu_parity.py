@@ -86,6 +86,33 @@ def test_deep_inbred_float32_rounding_stress(gen, oracle):
     assert phi.diagonal().min() > 0.9
 
 
+def test_fused_small_levels_match_per_level_launches(gen, oracle, monkeypatch):
+    """Runs of level steps with cuts <= 128 members go through ONE persistent launch
+    (levels_small_kernel, both matrices in LDS); bit-equal to per-level launches and the oracle."""
+    from genlib_jl_amd import synth
+    for args in ((200, 50, 3), (60, 120, 5), (40, 128, 7), (25, 130, 4)):      # 130: cuts straddle the limit
+        ind, fa, mo, sex, pro = synth.deep_inbred(*args)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        monkeypatch.delenv("GENPHI_NO_SMALL", raising=False)
+        pl = gen.plan(ped, pro)
+        fused = pl.compute(timing=True)
+        ms = [pl.stats.level_ms[k] for k in range(pl.stats.n_steps)]
+        sizes = pl.levels()[0]
+        pl.close()
+        _assert_equal(fused, want)
+        if max(sizes[:-1]) <= 128:
+            assert sum(1 for t in ms[:-1] if t == 0.0) >= len(ms) - 2, "the fused run books its time on one step"
+        monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+        pl = gen.plan(ped, pro)
+        _assert_equal(pl.compute(), want)
+        pl.close()
+    monkeypatch.delenv("GENPHI_NO_SMALL", raising=False)
+    # the top levels of a real pedigree are small too (genea140 starts at 10 founders)
+    ped = gen.genealogy(gen.genea140)
+    _assert_equal(gen.phi(ped), np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy")))
+
+
 def test_subnormal_kinship_rare_branch(gen, oracle):
     """Kinships below 2^-126 must be stored as Float32 subnormals exactly like the reference
     (no flush-to-zero), and below 2^-149 round to zero the same way."""
