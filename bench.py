@@ -220,6 +220,15 @@ def main():
         lvl_kernel = lvl.copy()
         if len(lvl_kernel):
             lvl_kernel[-1] -= perm_ms / K                 # the proband-order pass is a different kernel
+        # the kernel that dominates the step: by accumulated time over the level steps of each kind
+        modes = pl.step_modes()
+        names = {0: "level_full_kernel", 1: "level_split_kernel", 2: "level_half_kernel"}
+        by_kernel = {}
+        for k, t in enumerate(lvl_kernel):
+            small = k < len(lvl_kernel) - 1 and sizes[k] <= 128 and sizes[k + 1] <= 128 and args.kernel == 0
+            nm = "level_naive_kernel" if args.kernel == 1 else ("levels_small_kernel" if small else names.get(modes[k], "?"))
+            by_kernel[nm] = by_kernel.get(nm, 0.0) + float(t)
+        dominant = max(by_kernel, key=by_kernel.get) if by_kernel else "level_split_kernel"
         tot_b, tot_ms = float(sum(byt)), float(lvl_kernel.sum())
         achieved = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         traffic = None
@@ -242,7 +251,7 @@ def main():
                        "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
                        "level_ms": [round(float(x), 4) for x in lvl] if len(lvl) <= 64 else None,
                        "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
-            "roofline": {"bound": "hbm", "kernel": "level_split_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),

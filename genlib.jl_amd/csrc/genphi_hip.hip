@@ -28,7 +28,8 @@
 //   level_naive_kernel             one thread per entry, four global gathers (reference
 //       kernel for A/B comparisons; opts.kernel = 1).
 //   colperm_kernel                 proband-order delivery of a final level computed in
-//       locality order (HALF mode only).
+//       locality order (HALF mode only): source row staged through LDS in segments, the
+//       chunk's perm words and values in registers, coalesced 16-byte loads and stores.
 //   No MFMA anywhere: this is a gather-average, HBM-bound.
 #include <hip/hip_runtime.h>
 
@@ -710,12 +711,51 @@ __global__ void row_sums_kernel(const float *m, long long ld, int n, int row_beg
 }
 
 // out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
-__global__ void colperm_kernel(const float *in, float *out, long long ld, int n, const int *perm)
+// A per-element global gather runs at ~0.4 TB/s (one cache line per lane).  Here a workgroup
+// owns (row, column chunk): it keeps the chunk's perm words and output values in registers,
+// stages the source row through LDS one segment at a time (16-byte coalesced loads), picks the
+// elements that fall in the segment, and writes the chunk with 16-byte coalesced stores.
+template <int CPT>
+__global__ void __launch_bounds__(1024)
+colperm_kernel(const float *__restrict__ in, float *__restrict__ out, long long ld, int n, const int *__restrict__ perm,
+               int n_chunks, int seg_floats, int n_segs)
 {
-    const long long c = (long long)blockIdx.y * blockDim.x + threadIdx.x;
-    const long long k = blockIdx.x;
-    if (c >= ld) return;
-    out[k * ld + c] = c < n ? in[k * ld + perm[c]] : 0.f;
+    extern __shared__ float lds[];
+    static_assert(CPT % 4 == 0, "columns are handled in quads");
+    constexpr int NQ = CPT / 4;
+    const int row = blockIdx.x / n_chunks, chunk = blockIdx.x - row * n_chunks;
+    const int tid = threadIdx.x;
+    const long long c0 = (long long)chunk * CPT * 1024;
+    const float *src = in + (long long)row * ld;
+    int pidx[CPT];
+    float val[CPT];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const long long j = c0 + ((long long)q * 1024 + tid) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pidx[4 * q + e] = (j + e < n) ? perm[j + e] : -1;       // -1: padding column, stays 0
+            val[4 * q + e] = 0.f;
+        }
+    }
+    for (int sg = 0; sg < n_segs; ++sg) {
+        const int base = sg * seg_floats;
+        const int len = min(seg_floats, (int)ld - base);             // ld is a multiple of 64
+        __syncthreads();                                            // previous segment fully consumed
+        stage_row<4>(lds, src + base, len >> 2, tid, 1024);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const unsigned t = (unsigned)(pidx[k] - base);
+            if (t < (unsigned)len) val[k] = lds[t];
+        }
+    }
+    float *dst = out + (long long)row * ld;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const long long j = c0 + ((long long)q * 1024 + tid) * 4;
+        if (j < ld) *reinterpret_cast<float4 *>(dst + j) = make_float4(val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]);
+    }
 }
 
 }  // namespace
@@ -1281,9 +1321,20 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     if (rc) return rc;
                     if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
                     if (need_perm) {
-                        dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((ldN + 255) / 256));
-                        hipLaunchKernelGGL(colperm_kernel, grid, dim3(256), 0, p->stream, p->final_tmp, p->result, ldN,
-                                           static_cast<int>(N), p->d_final_perm);
+                        // columns per thread (registers: 2 per column) and LDS segments of the source row
+                        const int per_thread = static_cast<int>((ldN + 1023) / 1024);
+                        const int n_chunks = (per_thread + 39) / 40;            // 40 columns per thread fit without spills
+                        const int cpt = ((per_thread + n_chunks - 1) / n_chunks + 3) / 4 * 4;
+                        const int seg_floats = 36864;
+                        const int n_segs = static_cast<int>((ldN + seg_floats - 1) / seg_floats);
+                        const size_t lds = static_cast<size_t>(std::min<int64_t>(seg_floats, ldN)) * sizeof(float);
+                        const dim3 grid(static_cast<unsigned>(n_rows * n_chunks));
+#define GENPHI_CP(C) if (cpt <= C) { HIP_TRY(set_max_lds(reinterpret_cast<const void *>(colperm_kernel<C>), lds)); \
+                        hipLaunchKernelGGL(colperm_kernel<C>, grid, dim3(1024), lds, p->stream, p->final_tmp, p->result, ldN, \
+                                           static_cast<int>(N), p->d_final_perm, n_chunks, seg_floats, n_segs); } else
+                        GENPHI_CP(8) GENPHI_CP(16) GENPHI_CP(24) GENPHI_CP(32) GENPHI_CP(40)
+                        return fail(GENPHI_ERR_ARG, "internal: colperm geometry");
+#undef GENPHI_CP
                         HIP_TRY(hipGetLastError());
                     }
                 }
