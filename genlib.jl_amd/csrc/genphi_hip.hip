@@ -671,6 +671,62 @@ levels_small_kernel(const SmallStep *__restrict__ steps, int n_run, const float 
     }
 }
 
+// ---- level step 0: the source matrix is Psi_1 = 1/2 I (src/compute.jl:271-274) -----------------
+// Nothing needs to be read from HBM: Psi_1[x][y] = 1/2 when x == y is a real member, else 0.  Same
+// per-entry arithmetic as level_naive_kernel with the four gathers replaced by index compares;
+// one workgroup per output row, 16-byte index loads and stores.  Saves the 1/2 I memset (0.4 ms at cfg4) and
+// every source-row read of the first level.
+__global__ void __launch_bounds__(256) level_identity_kernel(const LevelArgs p)
+{
+    const int w = blockIdx.x;                          // one workgroup per output row
+    const int i = p.rows[w];
+    const long long orow = p.out_rows ? p.out_rows[w] : i;
+    const int Ai = p.srcA[i], Bi = p.srcB[i], oi = p.ord[i];
+    const int none = p.n_prev;
+    auto h = [none](int x, int y) -> float { return (x == y && x != none) ? 0.5f : 0.f; };
+    float *orowp = p.out + orow * p.ld;
+    for (long long jq = (long long)threadIdx.x * 4; jq < p.ld; jq += 4 * blockDim.x) {
+        // an entry is non-zero only where row and column share a source (or on the diagonal):
+        // rare, so most waves take the all-zero path and the kernel runs at the speed of its stores
+        int Aj[4], Bj[4];
+        if (jq + 3 < p.n) {                            // index arrays are 256-byte aligned, jq % 4 == 0
+            const int4 a4 = *reinterpret_cast<const int4 *>(p.srcA + jq), b4 = *reinterpret_cast<const int4 *>(p.srcB + jq);
+            Aj[0] = a4.x; Aj[1] = a4.y; Aj[2] = a4.z; Aj[3] = a4.w;
+            Bj[0] = b4.x; Bj[1] = b4.y; Bj[2] = b4.z; Bj[3] = b4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = jq + e < p.n;
+                Aj[e] = in ? p.srcA[jq + e] : none; Bj[e] = in ? p.srcB[jq + e] : none;
+            }
+        }
+        bool hit[4], any = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long j = jq + e;
+            hit[e] = j < p.n && (j == i || (Ai != none && (Ai == Aj[e] || Ai == Bj[e])) || (Bi != none && (Bi == Aj[e] || Bi == Bj[e])));
+            any |= hit[e];
+        }
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (__any(any)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long j = jq + e;
+                if (hit[e]) {
+                    const int oj = p.ord[j];
+                    if (j == i && oi < 0) {
+                        v[e] = static_cast<float>(0.5 + 0.5 * static_cast<double>(h(Ai, Bi)));
+                    } else {
+                        const double sc = (oi < 0 ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
+                        v[e] = combine(h(Ai, Aj[e]), h(Ai, Bj[e]), h(Bi, Aj[e]), h(Bi, Bj[e]), (oi & kOrdMask) > (oj & kOrdMask), sc);
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(orowp + jq) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // Psi_1 = 1/2 I over the top founders (src/compute.jl:271-274); buffer pre-zeroed.
 __global__ void half_identity_kernel(float *m, long long ld, int n, const int *out_rows, int n_rows, int row_begin)
 {
@@ -1092,6 +1148,10 @@ static int block_size_for(int64_t n)
     return 512;       // 4 workgroups per CU overlap staging and gathers; 1024 threads measured 20 % slower (cfg3)
 }
 
+// level step 0 reads Psi_1 = 1/2 I: level_identity_kernel computes it from the indices alone
+// (GENPHI_NO_IDENTITY: test hook, the regular kernels on a materialised 1/2 I)
+static bool identity_source(int step) { return step == 0 && std::getenv("GENPHI_NO_IDENTITY") == nullptr; }
+
 static int launch_level(genphi_plan *p, int step, const float *psi, float *out, const int *rows,
                         const int *out_rows, int n_rows, int kernel, const int4 *desc, const int2 *grp, int n_groups)
 {
@@ -1114,6 +1174,10 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
     if (kernel == 1) {
         dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
         hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
+    } else if (identity_source(step)) {
+        hipLaunchKernelGGL(level_identity_kernel, dim3(static_cast<unsigned>(n_rows)), dim3(256), 0, p->stream, a);
+        if (out_rows == nullptr)         // intermediate level: its all-zero "none" row
+            HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
     } else if (s.mode == genphi::kModeFull) {
         a.lds_row = lds_row;
         const size_t lds = 2 * static_cast<size_t>(lds_row) * sizeof(float);
@@ -1275,12 +1339,16 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             HIP_TRY(hipGetLastError());
         } else {
             // Psi_1 = 1/2 I over the top founders
+            // (materialised only for kernels that read it: level_identity_kernel and the fused
+            //  small-level run start from the indices)
             const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
-            HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
-            hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
-                               p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
-                               static_cast<int>(n0), 0);
-            HIP_TRY(hipGetLastError());
+            if (kernel == 1 || !identity_source(0)) {
+                HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
+                hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
+                                   p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
+                                   static_cast<int>(n0), 0);
+                HIP_TRY(hipGetLastError());
+            }
             for (int s = 0; s < n_steps; ++s) {
                 const LevelStep &st = pl.steps[s];
                 const float *psi = p->buf[s & 1];

@@ -113,6 +113,34 @@ def test_fused_small_levels_match_per_level_launches(gen, oracle, monkeypatch):
     _assert_equal(gen.phi(ped), np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy")))
 
 
+def test_first_level_from_indices_matches_materialised_identity(gen, oracle, monkeypatch):
+    """Level step 0 reads Psi_1 = 1/2 I (src/compute.jl:271-274): level_identity_kernel computes
+    it from the index arrays alone; the regular kernels on a materialised 1/2 I must agree."""
+    from genlib_jl_amd import synth
+    cases = [synth.random_mating(6000, 500, 4, skip_permille=100),      # step 0 in FULL mode, dragged rows
+             synth.random_mating(40_000, 3000, 3),                      # wide first cut
+             ]
+    n = 700                                                             # founders only: no level step at all
+    cases.append((np.arange(1, n + 1), np.zeros(n, np.int64), np.zeros(n, np.int64), np.ones(n, np.int64), np.arange(1, n + 1)))
+    ind, fa, mo, sex, _ = synth.random_mating(3000, 300, 2)
+    cases.append((ind, fa, mo, sex, ind[fa != 0][:200]))                # step 0 is also the last step
+    for ind, fa, mo, sex, pro in cases:
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("GENPHI_NO_IDENTITY", "1")
+            else:
+                monkeypatch.delenv("GENPHI_NO_IDENTITY", raising=False)
+            _assert_equal(_gpu_phi(gen, ind, fa, mo, sex, pro), want)
+    monkeypatch.delenv("GENPHI_NO_IDENTITY", raising=False)
+    ped = gen.genealogy(gen.geneaJi)
+    pl = gen.plan(ped)
+    full = pl.compute()
+    pl.compute_device(rows=(1, 3))                                       # sharded last level, small
+    assert np.array_equal(pl.result_to_host(), full[1:3])
+    pl.close()
+
+
 def test_subnormal_kinship_rare_branch(gen, oracle):
     """Kinships below 2^-126 must be stored as Float32 subnormals exactly like the reference
     (no flush-to-zero), and below 2^-149 round to zero the same way."""
