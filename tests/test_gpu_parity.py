@@ -195,6 +195,47 @@ def test_half_mode_forced_small_windows(gen, oracle, monkeypatch):
     pl.close()
 
 
+def test_row_shards_compute_only_their_ancestors(gen, oracle, monkeypatch):
+    """Multi-GPU partition: a rank computes, at every upper level, only the rows its shard of
+    the last level descends from.  Shards must still reassemble to the full matrix bit for bit,
+    in every kernel mode, and agree with the unpruned sweep."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(8000, 900, 9, skip_permille=40)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    n = len(pro)
+    cuts = [(0, 1), (1, 130), (130, 131), (131, 600), (600, n)]
+    for cap in (None, 2048, 300):                         # FULL / SPLIT / HALF on the same pedigree
+        if cap is None:
+            monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS", raising=False)
+        else:
+            monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+        for prune in (True, False):
+            if prune:
+                monkeypatch.delenv("GENPHI_NO_SHARD_PRUNE", raising=False)
+            else:
+                monkeypatch.setenv("GENPHI_NO_SHARD_PRUNE", "1")
+            pl = gen.plan(ped, pro)
+            parts = [pl.compute(rows=r) for r in cuts]
+            _assert_equal(np.concatenate(parts, axis=0), want)
+            _assert_equal(pl.compute(), want)             # back to the full sweep on the same plan
+            _assert_equal(pl.compute(rows=(5, 17)), want[5:17])
+            pl.close()
+    monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS", raising=False)
+    monkeypatch.delenv("GENPHI_NO_SHARD_PRUNE", raising=False)
+    # a shard really does less work above the last level: compare level times at cfg3 size
+    ind, fa, mo, sex, pro = synth.random_mating(100_000, 10_000, 20)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    pl.compute_device(timing=True)
+    full_ms = sum(pl.stats.level_ms[k] for k in range(10, pl.stats.n_steps - 1))
+    for _ in range(2):
+        pl.compute_device(rows=(0, 1250), timing=True)
+    shard_ms = sum(pl.stats.level_ms[k] for k in range(10, pl.stats.n_steps - 1))
+    pl.close()
+    assert shard_ms < 0.97 * full_ms, (shard_ms, full_ms)
+
+
 def test_properties_at_scale(gen):
     """cfg3 (1e5 individuals / 1e4 probands / 20 generations): too slow for the oracle in a
     unit test, so check size-independent properties: symmetry, diagonal range, the default
