@@ -213,3 +213,34 @@ def test_branching_matches_reference_checks_and_oracle(gen, oracle):
         a, b = gen.plan(gp, np.sort(pr)), gen.plan(sub, np.sort(pr))
         assert a.levels() == b.levels()
         a.close(); b.close()
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "phi_c_abi")
+    lib_dir = os.path.join(ROOT, "genlib.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "phi_c_abi.c"), "-o", exe, "-L", lib_dir, "-lgenphi",
+                           "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_c_abi_from_plain_c(gen, tmp_path):
+    """include/genphi.h is a real C header: a C11 program (examples/phi_c_abi.c) compiles against it
+    with -Werror, links libgenphi.so and levelises geneaJi (no GPU needed for --plan)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe, gen.geneaJi, "--plan"], capture_output=True, text=True, check=True).stdout
+    assert out.splitlines()[0] == "Step 1 of 7: 2 founders, 4 probands, 2 both."
+    assert len(out.splitlines()) == 7
+
+
+@pytest.mark.gpu
+def test_c_abi_from_plain_c_on_gpu(gen, tmp_path):
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe, gen.geneaJi], capture_output=True, text=True, check=True).stdout.splitlines()
+    rows = [[float(x) for x in line.split()] for line in out[7:10]]
+    assert rows == [[0.591796875, 0.37109375, 0.072265625], [0.37109375, 0.591796875, 0.072265625],
+                    [0.072265625, 0.072265625, 0.53515625]]                 # test/runtests.jl:50-52
+    assert out[10] == "phiMean 0.171875"                                       # :53
