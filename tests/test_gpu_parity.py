@@ -166,6 +166,11 @@ def test_edge_cases(gen, oracle):
         _assert_equal(_gpu_phi(gen, ind, fa, mo, sex, pro), oped.phi(pro))
     # empty proband list
     assert gen.phi(gen.genealogy(tri), []).shape == (0, 0)
+    # IDs are Julia Int (64-bit) labels, not indices: sparse, huge and unordered IDs give the same matrix
+    big = {0: 0, **{i: (i * 0x1F3D5B79 + 7) % (1 << 61) + (1 << 40) for i in ind}}
+    ind2, fa2, mo2 = [big[i] for i in ind], [big[i] for i in fa], [big[i] for i in mo]
+    for pro in ([7, 6, 4, 2], [6, 7, 3]):
+        _assert_equal(_gpu_phi(gen, ind2, fa2, mo2, sex, [big[i] for i in pro]), oped.phi(pro))
 
 
 def test_half_mode_forced_small_windows(gen, oracle, monkeypatch):
