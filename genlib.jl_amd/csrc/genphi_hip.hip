@@ -270,8 +270,11 @@ __device__ __forceinline__ void store_row4(float *row, unsigned row_bytes, unsig
 #endif
 #if GENPHI_WG_TIMES
 __device__ unsigned long long g_wg_times[1024][3];
-__device__ unsigned long long g_wg_phase[1024][8];   // summed ticks per stage phase (thread 0), [6] = stages, [7] = B stages
-#define GENPHI_PHASE(k) do { const unsigned long long t_ = wall_clock64(); ph[k] += t_ - t_ph; t_ph = t_; } while (0)
+__device__ unsigned long long g_wg_clk[1024][2];      // shader-clock ticks (clock64) at start / end: effective frequency
+__device__ unsigned long long g_wg_phase[2][1024][16];   // [thread 0 | last thread]: ticks per phase, A stages in [0..5], B stages in [8..13]; [6] / [7] = A / B stage counts
+#define GENPHI_PHASE(k) do { const unsigned long long t_ = wall_clock64(); \
+        if (threadIdx.x == 0 || threadIdx.x == NT - 1) atomicAdd(&dbgl[(threadIdx.x ? 16 : 0) + (k) + ph_b], (unsigned)(t_ - t_ph)); \
+        t_ph = t_; } while (0)
 #else
 #define GENPHI_PHASE(k) do { } while (0)
 #endif
@@ -318,7 +321,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
 #if GENPHI_WG_TIMES
     const unsigned long long t_start = wall_clock64();
-    if (threadIdx.x == 0 && p.dbg) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; }
+    if (threadIdx.x == 0 && p.dbg) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; g_wg_clk[blockIdx.x][0] = clock64(); }
 #endif
     if (cur_l >= n_items) return;
     int kc = 0;                                           // items this workgroup has started
@@ -358,7 +361,12 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
 
 #if GENPHI_WG_TIMES
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ph = wall_clock64();
+    // phase accumulators live in LDS (32 words behind the queue slots): no registers, no scratch
+    unsigned *dbgl = reinterpret_cast<unsigned *>(lds + p.slot_off) + 4;
+    if (threadIdx.x < 32) dbgl[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long t_ph = wall_clock64();
+    int ph_b = 0;                                         // 0: A stage, 8: B stage
 #endif
     for (;;) {
         // keep the per-column address arithmetic inside the loop: hoisted out it costs VGPRs
@@ -381,6 +389,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
         }
         GENPHI_PHASE(5);                                // stage bookkeeping
+#if GENPHI_WG_TIMES
+        ph_b = stage_is_a ? 0 : 8;
+#endif
         __syncthreads();                                // previous gathers are done with the buffer
         GENPHI_PHASE(0);
         if (stage_is_a && kc > 0) {
@@ -401,7 +412,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         __syncthreads();
         GENPHI_PHASE(2);
 #if GENPHI_WG_TIMES
-        ph[6] += 1; ph[7] += stage_is_a ? 0 : 1;
+        if (threadIdx.x == 0 || threadIdx.x == NT - 1) atomicAdd(&dbgl[(threadIdx.x ? 16 : 0) + (stage_is_a ? 6 : 7)], 1u);
 #endif
 
         // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
@@ -534,10 +545,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         }
     }
 #if GENPHI_WG_TIMES
-    if (threadIdx.x == 0 && p.dbg) {
-        g_wg_times[blockIdx.x][1] = wall_clock64(); g_wg_times[blockIdx.x][2] = kc;
-        for (int k = 0; k < 8; ++k) g_wg_phase[blockIdx.x][k] = ph[k];
-    }
+    if (threadIdx.x == 0 && p.dbg) { g_wg_times[blockIdx.x][1] = wall_clock64(); g_wg_times[blockIdx.x][2] = kc; g_wg_clk[blockIdx.x][1] = clock64(); }
+    __syncthreads();
+    if (threadIdx.x < 32 && p.dbg) g_wg_phase[threadIdx.x >> 4][blockIdx.x][threadIdx.x & 15] = dbgl[threadIdx.x];
 #endif
 }
 
@@ -1205,7 +1215,7 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         const int stg_inst = stg <= 2 ? 2 : (stg <= 4 ? 4 : (stg <= 6 ? 6 : (stg <= 7 ? 7 : (stg <= 8 ? 8 : 9))));
         // LDS must also absorb the unconditional over-write past the row's end
         const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
-        const size_t lds = lds_stage + 16;
+        const size_t lds = lds_stage + 16 + (GENPHI_WG_TIMES ? 128 : 0);
         a.slot_off = static_cast<int>(lds_stage / sizeof(float));
         const int per_thread = static_cast<int>((s.ld + nt - 1) / nt);       // the padding columns [n, ld) are written too
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
@@ -1698,9 +1708,13 @@ int genphi_debug_wg_times(unsigned long long *out /* [1024][3] */)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(unsigned long long) * 1024 * 3) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
 }
-int genphi_debug_wg_phases(unsigned long long *out /* [1024][8] */)
+int genphi_debug_wg_clk(unsigned long long *out /* [1024][2] */)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clk), sizeof(unsigned long long) * 1024 * 2) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
+}
+int genphi_debug_wg_phases(unsigned long long *out /* [2][1024][16] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), sizeof(unsigned long long) * 2 * 1024 * 16) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
 }
 #endif
 

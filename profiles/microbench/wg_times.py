@@ -27,14 +27,21 @@ print("cuts", pl.levels()[0], "step", k_, "ms", st.level_ms[k_])
 for x in range(8):
     m = np.arange(256) % 8 == x
     print(f"xcd {x}: start {start[m].min():8.1f}..{start[m].max():8.1f} us  end {end[m].min():9.1f}..{end[m].max():9.1f} us  items/WG {items[m].min():.0f}..{items[m].max():.0f}  total {items[m].sum():.0f}")
-ph = np.zeros((1024, 8), dtype=np.uint64)
+ck = np.zeros((1024, 2), dtype=np.uint64)
+L.genphi_debug_wg_clk.argtypes = [C.c_void_p]
+assert L.genphi_debug_wg_clk(ck.ctypes.data) == 0
+ck = ck[:256].astype(np.float64)
+mhz = (ck[:, 1] - ck[:, 0]) / ((t[:, 1] - t[:, 0]) / 100.0)
+print(f"shader clock during the kernel (clock64 ticks per wall-clock us): min {mhz.min():.0f}  median {np.median(mhz):.0f}  max {mhz.max():.0f} MHz")
+ph = np.zeros((2, 1024, 16), dtype=np.uint64)
 L.genphi_debug_wg_phases.argtypes = [C.c_void_p]
 assert L.genphi_debug_wg_phases(ph.ctypes.data) == 0
-ph = ph[:256].astype(np.float64)
-st_n = ph[:, 6].sum()
+ph = ph[:, :256].astype(np.float64)
 names = ["barrier 1 (others still gathering)", "wait prefetched row + LDS writes", "barrier 2", "index loads + prefetch issue",
-         "gathers + combine + stores", "bookkeeping"]
-print(f"stages {st_n:.0f} (B stages {ph[:, 7].sum():.0f}); mean us per stage by phase (thread 0 of each workgroup):")
-for k, nm in enumerate(names):
-    print(f"  {nm:40s} {ph[:, k].sum() / st_n / 100.0:7.3f}")
-print(f"  {'total':40s} {ph[:, :6].sum() / st_n / 100.0:7.3f}")
+         "gathers (+ combine + stores)", "bookkeeping"]
+for who, label in ((0, "thread 0 (wave 0)"), (1, "last thread (wave 15)")):
+    na, nb = ph[who, :, 6].sum(), ph[who, :, 7].sum()
+    print(f"{label}: {na:.0f} A stages, {nb:.0f} B stages; mean us per stage by phase   A stage   B stage")
+    for k, nm in enumerate(names):
+        print(f"  {nm:40s} {ph[who, :, k].sum() / max(na, 1) / 100.0:9.3f} {ph[who, :, 8 + k].sum() / max(nb, 1) / 100.0:9.3f}")
+    print(f"  {'total':40s} {ph[who, :, 0:6].sum() / max(na, 1) / 100.0:9.3f} {ph[who, :, 8:14].sum() / max(nb, 1) / 100.0:9.3f}")
