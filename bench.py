@@ -253,6 +253,11 @@ def main():
                        "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # context, not the headline: what this access pattern (whole 96 KB rows, 16-byte
+                         # accesses, 3 reads : 2 writes, no reuse) can move at all on this GPU, measured by
+                         # profiles/microbench/row_stream.hip; and the rate of the REAL traffic when known
+                         "measured_ceiling_GBs": 5350.0,
+                         "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),
                          "whole_step_frac": (pl.algorithmic_bytes / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
