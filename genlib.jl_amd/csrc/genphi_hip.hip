@@ -1187,7 +1187,12 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         a.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step ? 1 : 0;
     }
     a.zero_row = (out_rows == nullptr && kernel != 1 && s.mode != genphi::kModeHalf) ? 1 : 0;
-    if (n_rows <= 0) return GENPHI_OK;
+    if (n_rows <= 0) {
+        // nothing to compute (a row shard whose ancestors do not reach this level), but the next level
+        // still reads this level's all-zero "none" row for its parentless members
+        if (out_rows == nullptr) HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
+        return GENPHI_OK;
+    }
     const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
     if (kernel == 1) {
         dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
@@ -1364,6 +1369,10 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 const LevelStep &sv = pl.steps[st];                                // produces cut st+1 (n = sv.n)
                 std::vector<char> need_prev(sv.n_prev + 1, 0);
                 std::vector<int> &rw = host_rows[st];
+                if (const char *e = std::getenv("GENPHI_SHARD_FORCE")) {            // debugging aid: "step:row"
+                    int fs = -1, fr = -1;
+                    if (std::sscanf(e, "%d:%d", &fs, &fr) == 2 && fs == st && fr >= 0 && fr < static_cast<int>(need.size())) need[fr] = 1;
+                }
                 for (int32_t i : sv.work)                                           // keep the planner's reuse order
                     if (need[i]) {
                         rw.push_back(i);
@@ -1401,6 +1410,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
 
     // ---- the sweep: every launch of one gen.phi, in stream order ------------------------------
+    const int prune_min_step = std::getenv("GENPHI_SHARD_PRUNE_MIN_STEP") ? std::atoi(std::getenv("GENPHI_SHARD_PRUNE_MIN_STEP")) : 0;   // debugging aid
     const bool small_off = std::getenv("GENPHI_NO_SMALL") != nullptr;            // test hook: per-level launches only
     std::vector<int> ev_after(std::max(n_steps, 1));                             // event recorded after step k (timing)
     for (int k = 0; k < static_cast<int>(ev_after.size()); ++k) ev_after[k] = k + 1;
@@ -1452,7 +1462,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 }
                 if (!last) {
                     float *out = p->buf[(s + 1) & 1];
-                    if (p->sh_valid && p->sh_steps[s].rows)
+                    if (p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step)
                         rc = launch_level(p, s, psi, out, p->sh_steps[s].rows, nullptr, p->sh_steps[s].n_rows, kernel,
                                           p->sh_steps[s].desc, p->sh_steps[s].grp, p->sh_steps[s].n_groups);
                     else

@@ -228,6 +228,31 @@ def test_row_shards_compute_only_their_ancestors(gen, oracle, monkeypatch):
             pl.close()
     monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS", raising=False)
     monkeypatch.delenv("GENPHI_NO_SHARD_PRUNE", raising=False)
+    # a shard whose ancestry stops early: above that, its levels have NO rows to compute, but the
+    # level below still reads their all-zero "none" row for its parentless members (found by
+    # tests/stress_random.py: stale rows of the previous sweep were read instead)
+    deep = synth.deep_inbred(60, 30, 3)                                  # 60 generations, shared ancestry
+    shallow = synth.deep_inbred(12, 24, 2, seed=5)                       # an unrelated family, 12 generations
+    n1 = len(deep[0])
+    rel = lambda a: np.where(a > 0, a + n1, 0)                           # noqa: E731  (relabel its IDs)
+    ind = np.concatenate([deep[0], shallow[0] + n1])
+    fa = np.concatenate([deep[1], rel(shallow[1])])
+    mo = np.concatenate([deep[2], rel(shallow[2])])
+    sex = np.concatenate([deep[3], shallow[3]])
+    pro = np.concatenate([deep[4], shallow[4] + n1])
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    for small_off in (False, True):
+        if small_off:
+            monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+        pl = gen.plan(ped, pro)
+        _assert_equal(pl.compute(), want)                                # leaves every buffer full of old rows
+        k = len(deep[4])
+        _assert_equal(pl.compute(rows=(k, len(pro))), want[k:])          # only the shallow family
+        _assert_equal(pl.compute(rows=(0, k)), want[:k])
+        _assert_equal(pl.compute(rows=(k - 3, k + 5)), want[k - 3:k + 5])
+        pl.close()
+    monkeypatch.delenv("GENPHI_NO_SMALL", raising=False)
     # a shard really does less work above the last level: compare level times at cfg3 size
     ind, fa, mo, sex, pro = synth.random_mating(100_000, 10_000, 20)
     ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
