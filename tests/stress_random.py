@@ -35,6 +35,18 @@ while time.time() - t0 < budget:
         parts = np.concatenate([pl.compute(rows=r) for r in ((0, a), (a, b), (b, N))], axis=0)
         ok = ok and np.array_equal(parts, want)
     modes = sorted(set(pl.step_modes()))
+    # the same plan again (hipGraph replay from the second untimed sweep on), the naive kernel,
+    # point lookups and the on-device sums
+    if rng.random() < 0.3:
+        ok = ok and np.array_equal(pl.compute(), want) and np.array_equal(pl.compute(), want)
+        ok = ok and np.array_equal(pl.compute(kernel=1), want)
+        if N:
+            r_, c_ = rng.integers(0, N, 5), rng.integers(0, N, 5)
+            pl.compute_device()
+            ok = ok and np.array_equal(pl.result_entries(r_, c_), want[r_, c_].astype(np.float64))
+            a_, d_, _ = pl.result_sums()
+            w64 = want.astype(np.float64)
+            ok = ok and abs(a_ - w64.sum()) <= 1e-9 * max(1.0, w64.sum()) and abs(d_ - np.trace(w64)) <= 1e-9 * max(1.0, np.trace(w64))
     pl.close()
     cases += 1
     if not ok:
