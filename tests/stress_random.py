@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0, cases, fails = time.time(), 0, 0
 while time.time() - t0 < budget:
-    n = int(rng.choice([30, 120, 400, 900, 1500]))
+    n = int(rng.choice([30, 120, 400, 900, 1500, 1500, 4000]))
     pf, p1, ps = rng.choice([0.01, 0.05, 0.3]), rng.choice([0.0, 0.1, 0.3]), rng.choice([0.0, 0.05])
     back = int(rng.choice([5, 50, 400, n]))
     ind, fa, mo, sex = _random_pedigree(rng, n, pf, p1, ps, back)
@@ -49,6 +49,8 @@ while time.time() - t0 < budget:
             ok = ok and abs(a_ - w64.sum()) <= 1e-9 * max(1.0, w64.sum()) and abs(d_ - np.trace(w64)) <= 1e-9 * max(1.0, np.trace(w64))
     pl.close()
     cases += 1
+    if cases % 25 == 0:
+        print(f"... {cases} cases, {fails} mismatches, {time.time() - t0:.0f} s", flush=True)
     if not ok:
         fails += 1
         print("MISMATCH", dict(n=n, pf=pf, p1=p1, ps=ps, back=back, cap=int(cap), N=N, modes=modes), flush=True)
