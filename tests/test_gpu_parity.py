@@ -400,6 +400,17 @@ def test_random_pedigrees_bit_exact(gen, oracle, monkeypatch):
     assert cases == 30
 
 
+def test_random_stress_short(gen):
+    """A short fixed-seed run of tests/stress_random.py (random pedigree x kernel mode x proband
+    subset x three random row shards x replay / naive kernel / lookups / sums, all against the
+    oracle); the long runs of that script are what found the empty-level bug of the shard pruning."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(HERE, "stress_random.py"), "25", "2024"], cwd=HERE,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " 0 mismatches" in out.stdout.splitlines()[-1]
+
+
 def test_graph_replay_matches_eager(gen, oracle):
     """The sweep is replayed from a captured hipGraph from the second untimed compute on:
     results must not change, also after switching shard / kernel and back."""
