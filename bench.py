@@ -249,6 +249,7 @@ def main():
                        "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
                        "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,
                        "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
+                       "unordered_pairs_per_s": (n * (n + 1) // 2) / (wall / K),      # N(N+1)/2 entries
                        "level_ms": [round(float(x), 4) for x in lvl] if len(lvl) <= 64 else None,
                        "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
