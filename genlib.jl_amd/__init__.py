@@ -9,6 +9,9 @@ meaning, printed lines and error behaviour as the reference:
     ped = gen.genealogy(gen.geneaJi)       # src/create.jl:161-189 (+ depth sort :196-254)
     gen.pro(ped); gen.founder(ped)         # src/identify.jl:35-39, :15-19
     phi = gen.phi(ped, verbose=True)       # src/compute.jl:233-304 -> float32 (N, N)
+    gen.phiMean(phi)                       # src/compute.jl:454-459 (PhiPlan.phi_mean(): on the device)
+    gen.f(ped, [1])                        # src/compute.jl:500-511, from one GPU sweep over the parents
+    gen.branching(ped, pro=[1])            # src/extract.jl:65-186, native pruning (csrc/loader.cpp)
 
 All kinship arithmetic runs in hand-written HIP kernels behind the C-ABI in
 include/genphi.h (csrc/genphi_hip.hip); there is no CPU fallback.
