@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -245,7 +246,10 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 #endif
 __device__ __forceinline__ void store_row4(float *row, unsigned row_bytes, unsigned byte_off, f4_t v)
 {
-#if GENPHI_STORE_AUX == 0
+#if GENPHI_STORE_AUX == 0 && defined(GENPHI_STORE_NT)
+    (void)row_bytes;                   // experiment: non-temporal row stores (streamed output should not evict source rows from L2)
+    __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(reinterpret_cast<char *>(row) + byte_off));
+#elif GENPHI_STORE_AUX == 0
     (void)row_bytes;
     st_off<f4_t>(row, byte_off, v);
 #else
@@ -895,7 +899,13 @@ struct genphi_plan {
     int *d_queues = nullptr;        // 8 work-queue counters per level step
     SmallStep *d_small = nullptr;   // one entry per level step (levels_small_kernel)
     hipGraphExec_t graph_exec = nullptr;   // captured sweep (see genphi_compute_device)
-    long long graph_key[4] = {0, 0, 0, 0}, eager_key[4] = {0, 0, 0, 0};
+    // key = (kernel, r0, r1, need_perm, alloc_gen).  A captured graph bakes raw device pointers into
+    // its kernel nodes, so every (re)allocation of a buffer the sweep touches bumps alloc_gen:
+    // the stale graph can then never be replayed, and a fresh eager run precedes the next capture.
+    long long graph_key[5] = {0, 0, 0, 0, 0}, eager_key[5] = {0, 0, 0, 0, 0};
+    long long alloc_gen = 1;
+    char *scratch = nullptr;               // genphi_result_sums / _entries staging (grown on demand)
+    size_t scratch_bytes = 0;
     bool eager_valid = false;
     int4 *d_shard_desc = nullptr;
     int2 *d_shard_grp = nullptr;
@@ -919,6 +929,17 @@ struct genphi_plan {
     size_t pin_bytes = 0;
 };
 
+static void drop_graph(genphi_plan *p)
+{
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    std::memset(p->graph_key, 0, sizeof(p->graph_key));
+    p->eager_valid = false;
+    ++p->alloc_gen;
+}
+
+// Releases everything the plan holds on its device and returns it to the "never uploaded" state:
+// every pointer nulled, every size / capacity / cache key reset, so that a later upload (same or
+// another device) starts from scratch instead of trusting stale pointers.
 static void free_device(genphi_plan *p)
 {
     if (!p->on_device) return;
@@ -926,25 +947,26 @@ static void free_device(genphi_plan *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     p->events.clear();
-    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-    p->eager_valid = false;
-    (void)hipFree(p->idx_blob);
-    (void)hipFree(p->d_shard_rows);
-    (void)hipFree(p->d_shard_out_rows);
-    (void)hipFree(p->d_shard_desc);
-    (void)hipFree(p->d_queues);
-    (void)hipFree(p->d_small);
-    (void)hipFree(p->sh_blob); p->sh_blob = nullptr; p->sh_valid = false;
-    (void)hipFree(p->d_shard_grp);
-    (void)hipFree(p->buf[0]);
-    (void)hipFree(p->buf[1]);
-    (void)hipFree(p->result);
-    (void)hipFree(p->final_tmp);
+    drop_graph(p);
+    auto release = [](auto *&ptr) { if (ptr) (void)hipFree(ptr); ptr = nullptr; };
+    release(p->idx_blob);
+    release(p->d_shard_rows); release(p->d_shard_out_rows); release(p->d_shard_desc); release(p->d_shard_grp);
+    release(p->d_queues); release(p->d_small); release(p->sh_blob); release(p->scratch);
+    release(p->buf[0]); release(p->buf[1]); release(p->result); release(p->final_tmp);
+    p->d_final_perm = nullptr;                       // lived inside idx_blob
+    p->dsteps.clear(); p->sh_steps.clear();
+    p->sh_valid = false; p->shard_groups = 0;
+    p->shard_cap = 0; p->shard_r0 = p->shard_r1 = -1;
+    p->buf_floats[0] = p->buf_floats[1] = 0;
+    p->result_floats = p->final_tmp_floats = 0; p->scratch_bytes = 0;
+    p->res_ld = 0; p->res_row_begin = 0; p->res_n_rows = 0;
     for (void *q : p->pin) (void)hipHostFree(q);
     for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
     p->pin.clear(); p->pin_streams.clear(); p->pin_bytes = 0;
     if (p->stream) (void)hipStreamDestroy(p->stream);
+    p->stream = nullptr;
     p->on_device = false;
+    p->device = -1;
 }
 
 extern "C" {
@@ -1101,28 +1123,48 @@ static int upload_plan(genphi_plan *p, int device)
     return GENPHI_OK;
 }
 
-static int ensure_floats(float **ptr, size_t *have, size_t need)
+static int ensure_floats(genphi_plan *p, float **ptr, size_t *have, size_t need)
 {
     if (*have >= need && *ptr) return GENPHI_OK;
+    drop_graph(p);                                   // a captured sweep points at the old buffer
     if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(float)));
     *have = need;
     return GENPHI_OK;
 }
 
+static int ensure_scratch(genphi_plan *p, size_t bytes)
+{
+    if (p->scratch_bytes >= bytes && p->scratch) return GENPHI_OK;
+    if (p->scratch) { HIP_TRY(hipFree(p->scratch)); p->scratch = nullptr; p->scratch_bytes = 0; }
+    const size_t want = std::max<size_t>(bytes, size_t(1) << 16);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->scratch), want));
+    p->scratch_bytes = want;
+    return GENPHI_OK;
+}
+
 static hipError_t set_max_lds(const void *fn, size_t bytes)
 {
-    // dynamic LDS above 64 KB has to be opted into per kernel; remember the largest request
-    static std::vector<std::pair<const void *, size_t>> seen;
-    for (auto &e : seen) {
-        if (e.first == fn) {
-            if (e.second >= bytes) return hipSuccess;
-            e.second = bytes;
-            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    // dynamic LDS above 64 KB has to be opted into per kernel AND per device; remember the largest
+    // request of each (device, kernel).  Plans on distinct devices may run on distinct host threads.
+    struct Seen { int device; const void *fn; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Seen &x : seen) {
+        if (x.device == dev && x.fn == fn) {
+            if (x.bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+            if (e == hipSuccess) x.bytes = bytes;
+            return e;
         }
     }
-    seen.emplace_back(fn, bytes);
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e == hipSuccess) seen.push_back({dev, fn, bytes});
+    return e;
 }
 
 // ---- SPLIT kernel instantiation table ---------------------------------------------------------
@@ -1288,16 +1330,17 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
 
     const int64_t N = pl.n_pro, ldN = pl.ld[L - 1], n_rows = r1 - r0;
-    rc = ensure_floats(&p->result, &p->result_floats, static_cast<size_t>(n_rows * ldN));
+    rc = ensure_floats(p, &p->result, &p->result_floats, static_cast<size_t>(n_rows * ldN));
     if (rc) return rc;
     p->res_ld = ldN;
     const bool need_perm = !pl.final_perm.empty();
     if (need_perm) {
-        rc = ensure_floats(&p->final_tmp, &p->final_tmp_floats, static_cast<size_t>(n_rows * ldN));
+        rc = ensure_floats(p, &p->final_tmp, &p->final_tmp_floats, static_cast<size_t>(n_rows * ldN));
         if (rc) return rc;
     }
     // shard row lists for the last step: storage row of proband r, output row r - r0
     if (n_rows > p->shard_cap) {
+        drop_graph(p);
         if (p->d_shard_rows) {
             HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows));
             HIP_TRY(hipFree(p->d_shard_desc)); HIP_TRY(hipFree(p->d_shard_grp));
@@ -1309,6 +1352,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
+        drop_graph(p);                               // shard lists and sh_blob are rewritten / reallocated below
         // work order of the shard: the planner's reuse order (sibling groups, chained along
         // shared B sources) restricted to the shard's rows
         std::vector<int> rows(n_rows), orows(n_rows);
@@ -1507,7 +1551,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     // opts kernels into their LDS), the sweep is captured into a hipGraph and replayed.
     // Timing runs stay eager (they need events between the launches).
     static const bool graphs_off = std::getenv("GENPHI_NO_GRAPH") != nullptr;
-    const long long key[4] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0};
+    const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0, p->alloc_gen};
     const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
     const bool use_graph = !timing && !graphs_off && !(opts && (opts->reserved & 1)) && same_as_eager && n_steps >= 8;
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
@@ -1662,8 +1706,9 @@ int genphi_result_sums(genphi_plan *p, double *sum_all, double *sum_diag, int64_
     if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
     HIP_TRY(hipSetDevice(p->device));
     const int64_t nr = p->res_n_rows;
-    double *d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 2 * nr * sizeof(double)));
+    int rc = ensure_scratch(p, 2 * nr * sizeof(double));
+    if (rc) return rc;
+    double *d = reinterpret_cast<double *>(p->scratch);
     hipLaunchKernelGGL(row_sums_kernel, dim3(static_cast<unsigned>(nr)), dim3(256), 0, p->stream, p->result,
                        static_cast<long long>(p->res_ld), static_cast<int>(p->plan.n_pro), static_cast<int>(p->res_row_begin),
                        d, d + nr);
@@ -1671,7 +1716,6 @@ int genphi_result_sums(genphi_plan *p, double *sum_all, double *sum_diag, int64_
     std::vector<double> h(2 * nr);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, 2 * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_sums: ") + hipGetErrorString(e));
     double sa = 0.0, sd = 0.0;                      // fixed order: reproducible
     for (int64_t k = 0; k < nr; ++k) { sa += h[k]; sd += h[nr + k]; }
@@ -1695,11 +1739,12 @@ int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const 
         off[k] = static_cast<long long>(rows[k] - r0) * p->res_ld + cols[k];
     }
     HIP_TRY(hipSetDevice(p->device));
-    long long *d_off = nullptr;
-    double *d_val = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), n * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_val), n * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, p->stream);
+    const size_t off_bytes = (static_cast<size_t>(n) * sizeof(long long) + 255) / 256 * 256;
+    int rc = ensure_scratch(p, off_bytes + static_cast<size_t>(n) * sizeof(double));
+    if (rc) return rc;
+    long long *d_off = reinterpret_cast<long long *>(p->scratch);
+    double *d_val = reinterpret_cast<double *>(p->scratch + off_bytes);
+    hipError_t e = hipMemcpyAsync(d_off, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(gather_entries_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, p->stream,
                            p->result, d_off, n, d_val);
@@ -1707,8 +1752,6 @@ int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_val, n * sizeof(double), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    (void)hipFree(d_off);
-    (void)hipFree(d_val);
     if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_entries: ") + hipGetErrorString(e));
     return GENPHI_OK;
 }
