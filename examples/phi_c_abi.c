@@ -2,8 +2,8 @@
  *
  *   gcc -std=c11 -O2 -I include examples/phi_c_abi.c -o phi_c_abi \
  *       -L genlib.jl_amd/lib -lgenphi -Wl,-rpath,$PWD/genlib.jl_amd/lib
- *   ./phi_c_abi tests/golden/geneaJi.csv          # prints the 3 x 3 matrix of test/runtests.jl:50-52
- *   ./phi_c_abi tests/golden/geneaJi.csv --plan   # levelisation only (works without a GPU)
+ *   ./phi_c_abi genlib.jl_amd/data/geneaJi.csv  # prints the 3 x 3 matrix of test/runtests.jl:50-52
+ *   ./phi_c_abi genlib.jl_amd/data/geneaJi.csv --plan  # levelisation only (works without a GPU)
  */
 #include <stdio.h>
 #include <stdlib.h>

@@ -9,8 +9,9 @@ meaning, printed lines and error behaviour as the reference:
     ped = gen.genealogy(gen.geneaJi)       # src/create.jl:161-189 (+ depth sort :196-254)
     gen.pro(ped); gen.founder(ped)         # src/identify.jl:35-39, :15-19
     phi = gen.phi(ped, verbose=True)       # src/compute.jl:233-304 -> float32 (N, N)
+    gen.phi(ped[1], ped[2])                # src/compute.jl:66-95: pairwise, Float64 (one Float64 GPU sweep)
     gen.phiMean(phi)                       # src/compute.jl:454-459 (PhiPlan.phi_mean(): on the device)
-    gen.f(ped, [1])                        # src/compute.jl:500-511, from one GPU sweep over the parents
+    gen.f(ped, [1])                        # src/compute.jl:500-511, from one Float64 GPU sweep over the parents
     gen.branching(ped, pro=[1])            # src/extract.jl:65-186, native pruning (csrc/loader.cpp)
 
 All kinship arithmetic runs in hand-written HIP kernels behind the C-ABI in
@@ -27,8 +28,35 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 
 # bundled example pedigrees (the reference exports the same names, src/GenLib.jl:27,43)
-geneaJi = os.path.join(_ROOT, "tests", "golden", "geneaJi.csv")
-genea140 = os.path.join(_ROOT, "tests", "golden", "genea140.csv")
+geneaJi = os.path.join(_HERE, "data", "geneaJi.csv")
+genea140 = os.path.join(_HERE, "data", "genea140.csv")
+
+
+class Individual:
+    """What `pedigree[ID]` returns (the reference's immutable Individual, src/create.jl:39-46):
+    enough of it for the path -- ID, rank, and the parents as handles (None = unknown)."""
+
+    def __init__(self, pedigree, ID, pos):
+        self.pedigree, self.ID, self.rank = pedigree, ID, pos + 1
+
+    def _parent(self, arr):
+        pid = int(arr[self.rank - 1])
+        return None if pid == 0 else self.pedigree[pid]
+
+    @property
+    def father(self):
+        return self._parent(self.pedigree.father)
+
+    @property
+    def mother(self):
+        return self._parent(self.pedigree.mother)
+
+    @property
+    def sex(self):
+        return int(self.pedigree.sex[self.rank - 1])
+
+    def __repr__(self):
+        return f"Individual({self.ID})"
 
 
 class Pedigree:
@@ -47,6 +75,10 @@ class Pedigree:
 
     def __len__(self):
         return len(self.ind)
+
+    def __getitem__(self, ID):
+        """pedigree[ID] -> Individual handle (src/create.jl:70); KeyError on an unknown ID."""
+        return Individual(self, int(ID), int(self.positions([ID])[0]))
 
     def _idx(self):
         if self._index is None:
@@ -157,13 +189,24 @@ def plan(pedigree, probandIDs=None):
 
 
 def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, kernel=0):
-    """gen.phi(pedigree, probandIDs = pro(pedigree); verbose=false, compute=true).
+    """gen.phi(pedigree, probandIDs = pro(pedigree); verbose=false, compute=true), or the pairwise
+    method gen.phi(individual_i, individual_j) (src/compute.jl:66-95) when called with two
+    `pedigree[ID]` handles: the Float64 kinship of the pair, from one Float64 level sweep on the GPU
+    (the reference's recursion is un-memoised and exponential on inbred pedigrees); bit-identical to
+    the recursion while kinships are exactly representable in Float64 (pedigrees less than ~26
+    generations deep), within 1e-15 relative beyond.
 
     Returns the square float32 matrix of pairwise kinship coefficients between probands
     (rows/columns in `probandIDs` order, duplicates collapsed), or None when compute=False.
     Prints the reference's cut-vertex lines (src/compute.jl:257-260, :281-284).
     Raises KeyError for an unknown proband ID.  Runs on the GPU (no CPU fallback).
     """
+    if isinstance(pedigree, Individual):
+        a, b = pedigree, probandIDs
+        if not isinstance(b, Individual) or b.pedigree is not a.pedigree:
+            raise TypeError("gen.phi(individual_i, individual_j) takes two individuals of one pedigree")
+        ped = a.pedigree
+        return float(_capi.phi_pairs(ped.ind, ped.father, ped.mother, [a.ID], [b.ID], device=device)[0])
     pl = plan(pedigree, probandIDs)
     try:
         sizes, both = pl.levels()
@@ -187,12 +230,13 @@ def f(pedigree, IDs, device=None):
     """gen.f(pedigree, IDs) (src/compute.jl:500-511): inbreeding coefficients (Float32 vector).
 
     F(x) = kinship of x's parents, 0 if a parent is unknown.  The reference evaluates each one
-    with the un-memoised pairwise recursion (:66-95), exponential on deep inbred pedigrees;
-    here ONE level sweep over the set of parents runs on the GPU and the (father, mother)
-    entries are read back (`genphi_result_entries`).  The reference rounds the exact Float64
-    value to Float32 once; the sweep rounds to Float32 at every level, so the two agree to
-    ~3e-8 and exactly whenever no level rounds (geneaJi: f(ped, [1]) == [0.18359375],
-    f(ped, [17]) == [0.], test/runtests.jl:47-48).
+    with the un-memoised Float64 pairwise recursion (:66-95), exponential on deep inbred
+    pedigrees, and rounds the result to Float32 once.  Here ONE level sweep over the set of
+    parents runs on the GPU with Float64 level matrices (GENPHI_FLAG_STORAGE_F64), the
+    (father, mother) entries are read back (`genphi_result_entries`) and rounded to Float32 once:
+    the same values bit for bit while kinships are exactly representable in Float64 (pedigrees
+    less than ~26 generations deep; beyond, within 1e-15 relative before the rounding).
+    test/runtests.jl:47-48: f(ped, [1]) == [0.18359375], f(ped, [17]) == [0.].
     """
     IDs = np.asarray(IDs, dtype=np.int64)
     pos = pedigree.positions(IDs)                       # KeyError on an unknown ID
@@ -204,8 +248,8 @@ def f(pedigree, IDs, device=None):
     parents = np.unique(np.concatenate([fa[both], mo[both]]))     # sorted, like a proband list
     pl = plan(pedigree, parents)
     try:
-        pl.compute_device(device=device)
-        out[both] = pl.result_entries(np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both]))
+        pl.compute_device(device=device, storage64=True)
+        out[both] = pl.result_entries(np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both])).astype(np.float32)
     finally:
         pl.close()
     return out
@@ -222,9 +266,12 @@ def branching(pedigree, pro=None, ancestors=None):
 
 
 def phiMean(phi_matrix):
-    """gen.phiMean(::Matrix{Float32}) (src/compute.jl:454-459): mean off-diagonal kinship,
-    accumulated in float32 like the reference (host-side; an on-device reduction is a
-    SURVEY.md 8(f) "next" row)."""
+    """gen.phiMean(::Matrix{Float32}) (src/compute.jl:454-459): mean off-diagonal kinship of a host
+    matrix, accumulated in float32 like the reference.  numpy's float32 pairwise summation blocks
+    differently from Julia's `sum`, so on large matrices the last bits can differ (about 1 ulp of
+    Float32; exact whenever the sums are exact, e.g. 0.171875 on geneaJi, test/runtests.jl:53).
+    `PhiPlan.phi_mean()` reduces the RESIDENT matrix on the device instead (Float64 accumulation,
+    one rounding; no 40 GB device-to-host copy at N = 1e5)."""
     m = np.asarray(phi_matrix, dtype=np.float32)
     total = np.float32(m.sum(dtype=np.float32))
     diagonal = np.float32(np.diagonal(m).sum(dtype=np.float32))

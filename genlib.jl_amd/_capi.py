@@ -20,6 +20,8 @@ GENPHI_ERR_DEVICE = 5
 GENPHI_ERR_ARG = 6
 
 GENPHI_MAX_STAT_LEVELS = 1024
+GENPHI_FLAG_NO_GRAPH = 1
+GENPHI_FLAG_STORAGE_F64 = 2
 
 _I64P = C.POINTER(C.c_int64)
 _F32P = C.POINTER(C.c_float)
@@ -38,10 +40,12 @@ class GenphiStats(C.Structure):
 
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode",
+    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info",
     "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
-    "genphi_result_to_host", "genphi_result_sums", "genphi_result_entries", "genphi_compute_f32",
-    "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_destroy", "genphi_last_error",
+    "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
+    "genphi_compute_f32",
+    "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
+    "genphi_last_error",
     "genphi_version",
 ]
 
@@ -72,6 +76,8 @@ def lib():
         L.genphi_plan_n_probands.restype = C.c_int64
         L.genphi_plan_step_mode.argtypes = [C.c_void_p, C.c_int32]
         L.genphi_plan_step_mode.restype = C.c_int
+        L.genphi_plan_step_info.argtypes = [C.c_void_p, C.c_int32, _I64P]
+        L.genphi_plan_step_info.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -80,6 +86,10 @@ def lib():
         L.genphi_result_device.restype = C.c_int
         L.genphi_result_to_host.argtypes = [C.c_void_p, _F32P]
         L.genphi_result_to_host.restype = C.c_int
+        L.genphi_result_to_host_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.genphi_result_to_host_f64.restype = C.c_int
+        L.genphi_phi_pairs.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double), C.c_int32]
+        L.genphi_phi_pairs.restype = C.c_int
         L.genphi_result_sums.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), _I64P]
         L.genphi_result_sums.restype = C.c_int
         L.genphi_result_entries.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double)]
@@ -94,6 +104,8 @@ def lib():
         L.genphi_genealogy_read.restype = C.c_int
         L.genphi_free.argtypes = [C.c_void_p]
         L.genphi_free.restype = None
+        L.genphi_plan_release_device.argtypes = [C.c_void_p]
+        L.genphi_plan_release_device.restype = C.c_int
         L.genphi_plan_destroy.argtypes = [C.c_void_p]
         L.genphi_plan_destroy.restype = None
         L.genphi_last_error.restype = C.c_char_p
@@ -183,6 +195,12 @@ class PhiPlan:
             lib().genphi_plan_destroy(self._h)
             self._h = None
 
+    def release_device(self):
+        """Free the plan's GPU memory; the next compute uploads again (same or another device)."""
+        rc = lib().genphi_plan_release_device(self._h)
+        if rc:
+            _raise(rc)
+
     def __del__(self):
         try:
             self.close()
@@ -207,27 +225,39 @@ class PhiPlan:
         n = nl.value
         return [int(cs[k]) for k in range(n)], [int(bc[k]) for k in range(max(n - 1, 0))]
 
+    def step_info(self, step):
+        """(mode, dragged members, distinct parents of the new members, new x new sub-step mode) of a level step."""
+        out = (C.c_int64 * 4)()
+        rc = lib().genphi_plan_step_info(self._h, int(step), out)
+        if rc:
+            _raise(rc)
+        return tuple(int(x) for x in out)
+
     def step_modes(self):
-        """Kernel variant per level step: 0 FULL, 1 SPLIT, 2 HALF."""
+        """Kernel family per level step: 0 FULL, 1 SPLIT, 2 WIDE."""
         n = len(self.levels()[0]) - 1
         return [int(lib().genphi_plan_step_mode(self._h, k)) for k in range(max(n, 0))]
 
-    def _opts(self, device, kernel, rows, timing):
+    def _opts(self, device, kernel, rows, timing, storage64=False, no_graph=False):
         o = GenphiOpts()
         o.device = -1 if device is None else int(device)
         o.kernel = int(kernel)
         o.row_begin, o.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
         o.timing = 1 if timing else 0
+        o.reserved = (GENPHI_FLAG_STORAGE_F64 if storage64 else 0) | (GENPHI_FLAG_NO_GRAPH if no_graph else 0)
         return o
 
-    def compute_device(self, device=None, kernel=0, rows=None, timing=False):
-        """Run all level steps on the GPU; the result stays resident in HBM."""
-        o = self._opts(device, kernel, rows, timing)
+    def compute_device(self, device=None, kernel=0, rows=None, timing=False, storage64=False, no_graph=False):
+        """Run all level steps on the GPU; the result stays resident in HBM.  storage64: Float64
+        level matrices (the values of the reference's Float64 pairwise recursion)."""
+        o = self._opts(device, kernel, rows, timing, storage64, no_graph)
         st = GenphiStats()
         rc = lib().genphi_compute_device(self._h, C.byref(o), C.byref(st))
         if rc:
             _raise(rc)
         self.stats = st
+        self._rows = (self.n_probands if rows is None or int(rows[1]) <= 0 else int(rows[1]) - int(rows[0]))
+        self._f64 = bool(storage64)
         return st
 
     def result_device(self):
@@ -239,13 +269,25 @@ class PhiPlan:
         return ptr.value, ld.value, r0.value, nr.value
 
     def result_to_host(self):
-        _, _, _, nr = self.result_device()
+        nr = self._rows if getattr(self, "_f64", False) else self.result_device()[3]
         n = self.n_probands
         out = np.empty((nr, n), dtype=np.float32)
         rc = lib().genphi_result_to_host(self._h, out.ctypes.data_as(_F32P))
         if rc:
             _raise(rc)
         return out
+
+    def result_to_host_f64(self):
+        """The resident Float64 result (after compute_device(storage64=True)) as float64 (rows, N)."""
+        n = self.n_probands
+        out = np.empty((self._resident_rows(), n), dtype=np.float64)
+        rc = lib().genphi_result_to_host_f64(self._h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc:
+            _raise(rc)
+        return out
+
+    def _resident_rows(self):
+        return self._rows if getattr(self, "_rows", None) is not None else self.n_probands
 
     def result_sums(self):
         """(sum of all resident entries, sum of their diagonal entries, resident rows), Float64,
@@ -279,3 +321,18 @@ class PhiPlan:
     def compute(self, device=None, kernel=0, rows=None, timing=False):
         self.compute_device(device=device, kernel=kernel, rows=rows, timing=timing)
         return self.result_to_host()
+
+
+def phi_pairs(ind, father, mother, id_i, id_j, device=None):
+    """Float64 kinship of each pair (id_i[k], id_j[k]) (genphi_phi_pairs: one Float64 sweep)."""
+    L = lib()
+    ind, father, mother, id_i, id_j = _i64(ind), _i64(father), _i64(mother), _i64(id_i), _i64(id_j)
+    if id_i.shape != id_j.shape or id_i.ndim != 1:
+        raise ValueError("id_i and id_j must be 1-D and of equal length")
+    out = np.empty(len(id_i), dtype=np.float64)
+    rc = L.genphi_phi_pairs(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P),
+                            len(id_i), id_i.ctypes.data_as(_I64P), id_j.ctypes.data_as(_I64P),
+                            out.ctypes.data_as(C.POINTER(C.c_double)), -1 if device is None else int(device))
+    if rc:
+        _raise(rc)
+    return out

@@ -19,17 +19,20 @@
 //   level_split_kernel  cuts of ~20k..40k members (two rows no longer fit in 160 KB of LDS):
 //       row A is staged, the A-row terms of every column go to registers, row B is staged
 //       into the same buffer, the B-row terms are gathered, combined and the row written.
-//   level_half_kernel   fallback above ~40k members: only a window of the B-side (mother)
-//       columns is staged; the A-side (father) terms are read straight from HBM/L2 -- the
-//       planner stores the columns sorted by A inside each window bucket.
+//   WIDE levels (a source row no longer fits in LDS, > ~36.8k members): the cut is stored
+//       [dragged..., new...] and the level matrix is assembled block by block from streaming
+//       passes: rows_compact_kernel (dragged x dragged = a stream compaction of the previous
+//       matrix; new x dragged = the compacted half sum of two rows; the parent x parent matrix),
+//       transpose_block_kernel (dragged x new), a FULL / SPLIT sub-step on the compacted parent
+//       matrix (new x new), copy_block_kernel, pad_zero_kernel.
 //   levels_small_kernel a RUN of consecutive steps with cuts <= 128 members in one persistent
 //       launch: both level matrices live in LDS, one barrier per level (deep small pedigrees
 //       are launch-bound otherwise).
 //   level_naive_kernel             one thread per entry, four global gathers (reference
 //       kernel for A/B comparisons; opts.kernel = 1).
 //   colperm_kernel                 proband-order delivery of a final level computed in
-//       locality order (HALF mode only): source row staged through LDS in segments, the
-//       chunk's perm words and values in registers, coalesced 16-byte loads and stores.
+//       [dragged, new] order (WIDE last step only): source row staged through LDS in segments,
+//       the chunk's perm words and values in registers, coalesced 16-byte loads and stores.
 //   No MFMA anywhere: this is a gather-average, HBM-bound.
 #include <hip/hip_runtime.h>
 
@@ -47,7 +50,6 @@
 
 using genphi::LevelStep;
 using genphi::Plan;
-using genphi::Segment;
 
 // ---------------------------------------------------------------------------------------------
 // device code
@@ -77,6 +79,16 @@ __device__ __forceinline__ float combine_e(float a, float b, float c, float d, b
     return static_cast<float>(__builtin_ldexp(s, e));
 }
 
+// Exactness certificate of a level-matrix row: every entry is 0 or >= 2^-27 (entries are <= 1).
+// Such a Float32 is a multiple of 2^-50, so ANY partial sum of up to four of them is a multiple of
+// 2^-50 that is <= 4: exactly representable in Float64.  All groupings of the reference's
+// recursion then give the same, exact, sum, and the entry may be computed in
+// whatever order is cheapest -- the result is still bit-identical to the reference.  Rows without
+// the certificate go through the grouping-exact path.
+//   cert_key(v) = bits(v) - 1: 0 -> 0xffffffff (fine), anything below cert_thresh -> not certified
+// threshold word in LevelArgs::cert_thresh = bits(2^-27) - 1 = 0x31ffffff (a test hook may raise it)
+__device__ __forceinline__ unsigned cert_key(float v) { return __float_as_uint(v) - 1u; }
+
 __device__ __forceinline__ int xcd_remap(int b, int nwg)
 {
     // consecutive work items on one XCD (blocks b and b+8 share an XCD): rows that share a
@@ -95,10 +107,6 @@ struct LevelArgs {
     const int *rows;         // work list: storage row ids (n_rows entries)
     const int *out_rows;     // row of `out` for each work item; nullptr = same as storage row
     int n_rows;
-    // HALF mode
-    const Segment *segs;
-    const int *b_rel;
-    int n_segs;
     int lds_row;             // floats per staged row in LDS
     int chunk_cols;          // SPLIT: columns per chunk (multiple of blockDim)
     int n_chunks;            // SPLIT: column chunks per row (work item = sibling group x chunk)
@@ -106,6 +114,14 @@ struct LevelArgs {
     int slot_off;            // SPLIT: float offset in LDS of the two work-queue hand-over slots
     int dbg;                 // GENPHI_WG_TIMES builds: record this launch's workgroup timing
     int zero_row;            // !=0: this launch also zeroes the "none" row n of `out` (intermediate levels)
+    // exactness certificates (see cert_bad): one word per row of the previous / this level matrix,
+    // != 0 when the row holds an entry in (0, 2^-27); nullptr = not tracked
+    const int *cert_prev;
+    int *cert_out;
+    const int *glist;        // SPLIT: this launch's sibling groups, compacted on the device (nullptr = all of grp[])
+    unsigned chunk_magic;    // SPLIT: floor(2^32 / n_chunks) + 1, so that item / n_chunks = umulhi(item, chunk_magic); 0 when n_chunks == 1
+    const int *gcnt;         // SPLIT: [0] certified groups, [1] the others (of this launch's group list)
+    unsigned cert_thresh;    // bits of the smallest certified value minus one (test hook raises it)
 };
 
 // ---- shared pieces of the row kernels --------------------------------------------------------
@@ -174,6 +190,7 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
     if (r.hasB) stage_row<4>(sB, r.rowB, nvec, tid, nt);
     __syncthreads();
     const int e_ij = (r.new_i ? -1 : 0) - 1;       // every column has weight 1/2 (dragged: A = B = itself)
+    unsigned ck = 0xffffffffu;
     for (int j0 = tid; j0 < p.n; j0 += U * nt) {
         unsigned pk[U]; int oj[U];
 #pragma unroll
@@ -201,9 +218,14 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * nt;
-            if (j < p.n) r.orowp[j] = (j == r.i && r.new_i) ? r.diag : v[u];
+            if (j < p.n) {
+                const float val = (j == r.i && r.new_i) ? r.diag : v[u];
+                ck = min(ck, cert_key(val));
+                r.orowp[j] = val;
+            }
         }
     }
+    if (p.cert_out && ck < p.cert_thresh) p.cert_out[r.i] = 1;      // exactness certificate of the row (see cert_key)
     // zero columns [n, ld): the "none" column of this level and its pitch padding
     for (long long j = p.n + tid; j < p.ld; j += nt) r.orowp[j] = 0.f;
 }
@@ -246,8 +268,12 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 #endif
 __device__ __forceinline__ void store_row4(float *row, unsigned row_bytes, unsigned byte_off, f4_t v)
 {
-#if GENPHI_STORE_AUX == 0 && defined(GENPHI_STORE_NT)
-    (void)row_bytes;                   // experiment: non-temporal row stores (streamed output should not evict source rows from L2)
+#if GENPHI_STORE_AUX == 0 && !defined(GENPHI_STORE_PLAIN)
+    // non-temporal row stores: an output row is never re-read by this launch, so it should not push
+    // the source rows other workgroups are about to stage out of the XCD's L2 (same-box A/B on cfg4:
+    // 44.2 -> 42.2 ms; the 3 : 2 read : write ceiling of this access pattern rises 5.3 -> 5.8 TB/s,
+    // profiles/microbench/out/r02_*.out)
+    (void)row_bytes;
     __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(reinterpret_cast<char *>(row) + byte_off));
 #elif GENPHI_STORE_AUX == 0
     (void)row_bytes;
@@ -299,9 +325,13 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     // When its own slice is drained a workgroup goes on with the slices of the other XCDs
     // (same counters): the XCDs do not run at the same speed (the last one finished 8 % after
     // the first on the final level of cfg4), and a slice boundary is only a locality hint.
-    const int n_items = p.n_groups * p.n_chunks;
+    const int n_items = (p.gcnt ? p.gcnt[1] : p.n_groups) * p.n_chunks;
     const int xcd = blockIdx.x & 7;
     const int q = n_items >> 3, rem = n_items & 7;
+    // With certificates on (p.glist), this kernel owns the sibling groups with an uncertified
+    // source row and level_split_fast_kernel the others: group_split_kernel has compacted the two
+    // group lists on the device (glist = this kernel's groups, gcnt[1] = how many); when every
+    // group is certified this launch ends at once.
     auto draw = [&]() -> int {                            // global item index, or n_items when all is drawn
 #pragma unroll 1
         for (int t = 0; t < 8; ++t) {
@@ -315,6 +345,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         float *zr = p.out + (long long)p.n * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
+    if (n_items == 0) return;                             // nothing uncertified in this launch
+    // hand-over slots (item, group, A source, position in the group list): thread 0 resolves the
+    // item it has drawn (list indirection, group descriptor) off the critical path
     int *slot = reinterpret_cast<int *>(lds + p.slot_off);
     if (threadIdx.x == 0) {
         slot[0] = draw();
@@ -350,8 +383,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 
     // ---- stage state (all wave-uniform) ----
     int it = cur_l;                                       // current item
-    int g = it / p.n_chunks;
-    int chunk = it - g * p.n_chunks;
+    int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
+    int chunk = it - gk * p.n_chunks;
+    int g = p.glist ? p.glist[gk] : gk;
     int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
     int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
@@ -366,7 +400,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 
 #if GENPHI_WG_TIMES
     // phase accumulators live in LDS (32 words behind the queue slots): no registers, no scratch
-    unsigned *dbgl = reinterpret_cast<unsigned *>(lds + p.slot_off) + 4;
+    unsigned *dbgl = reinterpret_cast<unsigned *>(lds + p.slot_off) + 8;
     if (threadIdx.x < 32) dbgl[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long t_ph = wall_clock64();
@@ -407,7 +441,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         // next stage: B row of the next child that has one, else row A of the next item
         // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
         const int next_item = nxt_l;
-        const int gn = have_next ? next_item / p.n_chunks : g;
+        const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
+        const int gn = p.glist ? p.glist[gkn] : gkn;
         const int nextAi = grp[gn].y;
 #pragma unroll
         for (int k_ = 0; k_ < STG; ++k_)
@@ -480,6 +515,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             const int qk = w - wb;                      // which child of the group (wave-uniform)
             const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
+            unsigned ck = 0xffffffffu;                   // smallest cert_key of the entries written
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const unsigned jq = cb + q * 4 * NT + tl * 4;
@@ -492,9 +528,11 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                     const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
                     vq[e] = combine_e(pa[k], pb[k], c, d, i_hi, e_ij);
                 }
+                ck = min(ck, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ck));
                 // a ragged last quad spills into the padding columns [n, ld), zeroed afterwards
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
+            if (p.cert_out && ck < p.cert_thresh) p.cert_out[ri] = 1;         // plain store: the words only ever go 0 -> 1
             // the diagonal entry of a new member is patched by the thread that owns its column
             // (same thread as the quad store above, so the two stores stay ordered)
             if (new_i) {
@@ -516,6 +554,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             float *orowp = p.out + (long long)df.y * p.ld;
             const int e_ij = (new_f ? -1 : 0) - 1;
             const unsigned row_bytes = (unsigned)p.ld * 4u;
+            unsigned ckf = 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const unsigned jq = cb + q * 4 * NT + tlf * 4;
@@ -527,8 +566,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                                               __uint_as_float(__float_as_uint(pb[k]) ^ z1), 0.f, 0.f, true, e_ij);
                     vq[e] = (jq + e == (unsigned)df.x && new_f) ? 0.5f : v;
                 }
+                ckf = min(ckf, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ckf));
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
+            if (p.cert_out && ckf < p.cert_thresh) p.cert_out[df.x] = 1;
         }
 
         GENPHI_PHASE(4);                                // gathers, combine, row stores
@@ -539,8 +580,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         } else {                                        // next stage: row A of the next item
             if (!have_next) break;
             it = next_item;
-            g = gn;
-            chunk = it - g * p.n_chunks;
+            g = gn; gk = gkn;
+            chunk = it - gk * p.n_chunks;
             wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
             w = wb;
             stage_is_a = true;
@@ -555,48 +596,326 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 #endif
 }
 
-// ---- HALF: fallback for cuts too wide for one row in LDS (> ~40k members) --------------------
-// A window of the B-side columns is staged; A-side terms are read straight from HBM/L2 (the
-// planner sorts the columns by A inside each window bucket).  Needs colperm for the last level.
-__global__ void __launch_bounds__(1024) level_half_kernel(const LevelArgs p)
+// ---- SPLIT, certified rows: the grouping-free body ---------------------------------------------
+// Same work items, queue, pipeline and LDS use as level_split_kernel, for the sibling groups whose
+// source rows (A and every child's B) all carry the exactness certificate (cert_bad == 0): every
+// Float64 partial sum of an entry is then exact, so the reference's rank-dependent grouping cannot
+// change the result and the entry is simply  RN32( ((a + b) + (c + d)) / 4 ):
+//   stage A keeps  pab = (a + b) / 4  as ONE Float64 per column (the two registers that hold a and b
+//   in the grouping-exact kernel), stage B is  RN32( fma(c + d, 1/4, pab) )  -- 2 conversions, 1 add,
+//   1 fma, 1 conversion per entry instead of 4 + 3 + 1 + 1 and the grouping selects; no rank words,
+//   no per-child masks (so groups of up to 8 children in every level), fewer registers.
+// Bit-identical to the grouping-exact kernel on certified rows (tests force both on the same input).
+template <int NTHREADS, int CPT, int STG, bool CERT>
+__global__ void __launch_bounds__(NTHREADS)
+level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, int *queue)
 {
     extern __shared__ float lds[];
-    float *sA = lds;
-    float *sB = lds + p.lds_row;
-    const RowCtx r = row_setup(p);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    int cur_win = -1;
-    for (int s = 0; s < p.n_segs; ++s) {
-        const Segment sg = p.segs[s];
-        if (sg.win_begin != cur_win) {
-            if (cur_win >= 0) __syncthreads();          // everyone done with the old window
-            const int nvec = (sg.win_len + 3) >> 2;     // win_begin is a multiple of 4
-            stage_row<4>(sA, r.rowA + sg.win_begin, nvec, tid, nt);
-            if (r.hasB) stage_row<4>(sB, r.rowB + sg.win_begin, nvec, tid, nt);
-            __syncthreads();
-            if (tid == 0) { sA[sg.win_len] = 0.f; sB[sg.win_len] = 0.f; }   // the "none" slot
-            __syncthreads();
-            cur_win = sg.win_begin;
+    constexpr unsigned NT = NTHREADS;
+    float *sR = lds;
+    const int n_items = p.gcnt[0] * p.n_chunks;           // certified groups of this launch (group_split_kernel)
+    const int xcd = blockIdx.x & 7;
+    const int q = n_items >> 3, rem = n_items & 7;
+    auto draw = [&]() -> int {                            // next item of a certified group, or n_items
+#pragma unroll 1
+        for (int t = 0; t < 8; ++t) {
+            const int x = (xcd + t) & 7;
+            const int l = atomicAdd(&queue[x], 1);
+            if (l < q + (x < rem ? 1 : 0)) return x * q + min(x, rem) + l;
         }
-        if (r.hasB) {
-            for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
-                const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
-                const float a = r.rowA[Aj], c = r.rowB[Aj];
-                const float b = sA[br], d = sB[br];
-                float v = combine(a, b, c, d, r.ord_i > (oj & kOrdMask), r.sc_i * (oj < 0 ? 0.5 : 1.0));
-                if (j == r.i && r.new_i) v = r.diag;
-                r.orowp[j] = v;
-            }
+        return n_items;
+    };
+    if (p.zero_row && blockIdx.x == 0) {                  // the all-zero "none" row of this level
+        float *zr = p.out + (long long)p.n * p.ld;
+        for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
+    }
+    if (n_items == 0) return;                             // no certified group in this launch
+    // hand-over slots (item, group, A source, position in the group list): thread 0 resolves the
+    // item it has drawn (list indirection, group descriptor) off the critical path
+    int *slot = reinterpret_cast<int *>(lds + p.slot_off);
+    if (threadIdx.x == 0) {
+        slot[0] = draw();
+        slot[1] = draw();
+    }
+    __syncthreads();
+    int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);
+    int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
+    if (cur_l >= n_items) return;
+    int kc = 0;
+    unsigned tl = threadIdx.x;
+
+    f4_t pre[STG];
+    unsigned pk[CPT];                                     // A_j | B_j << 16 of this thread's columns
+    double pab[CPT];                                      // (a + b) / 4 of this thread's columns
+    static_assert(CPT % 4 == 0, "columns are handled in quads");
+    constexpr int NQ = CPT / 4;
+
+    int it = cur_l;
+    int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
+    int chunk = it - gk * p.n_chunks;
+    int g = p.glist ? p.glist[gk] : gk;
+    int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
+    int w = wb;
+    bool stage_is_a = true;
+    bool have_next = nxt_l < n_items;
+    unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
+
+#pragma unroll
+    for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
+
+    for (;;) {
+        asm volatile("" : "+v"(tl));
+        __builtin_assume(tl < NT);
+
+        // ---- part 0: scalar descriptors of the stage, ahead of the barriers ----
+        int4 dsc = make_int4(0, 0, 0, 0);
+        int nextB;
+        if (stage_is_a) {
+            nextB = desc[wb].z;
         } else {
-            for (int j = sg.col_begin + tid; j < sg.col_end; j += nt) {
-                const int Aj = p.srcA[j], br = p.b_rel[j], oj = p.ord[j];
-                float v = combine(r.rowA[Aj], sA[br], 0.f, 0.f, true, r.sc_i * (oj < 0 ? 0.5 : 1.0));
-                if (j == r.i && r.new_i) v = r.diag;
-                r.orowp[j] = v;
+            dsc = desc[w];
+            nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
+        }
+        __syncthreads();                                // previous gathers are done with the buffer
+        if (stage_is_a && kc > 0) {
+            nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
+            have_next = nxt_l < n_items;
+        }
+        const int next_item = nxt_l;
+        const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
+        const int gn = p.glist ? p.glist[gkn] : gkn;
+        const int nextAi = grp[gn].y;
+#pragma unroll
+        for (int k_ = 0; k_ < STG; ++k_)
+            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
+        __syncthreads();
+
+        // ---- part 1: index loads (before the prefetch: vmcnt retires in order), next stage's row ----
+        if (stage_is_a) {
+            if (threadIdx.x == 0) slot[kc & 1] = draw();
+            ++kc;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const u4_t v = ld_off<u4_t>(p.pk, (cb + q * 4 * NT + tl * 4) * 4u);
+                pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
             }
+        }
+        {
+            const float *src = p.psi + (long long)(nextB != p.n_prev ? nextB : nextAi) * p.ld_prev;
+#pragma unroll
+            for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+        }
+
+        // ---- part 2: gathers from the staged row ----
+        int wfin_b, wfin_e;
+        if (stage_is_a) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                pab[k] = (static_cast<double>(sR[pk[k] & 0xffff]) + static_cast<double>(sR[pk[k] >> 16])) * 0.25;
+            wfin_b = wb;
+            wfin_e = (nextB == p.n_prev) ? we : wb;
+        } else {
+            const int ri = dsc.x, orow = dsc.y;
+            float *orowp = p.out + (long long)orow * p.ld;
+            // a row with a B source is a new member with both parents: weight 1/2 x 1/2 per column
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
+            const unsigned row_bytes = (unsigned)p.ld * 4u;
+            unsigned ck = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned jq = cb + q * 4 * NT + tl * 4;
+                f4_t vq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
+                    const double cd = static_cast<double>(sR[pk[k] & 0xffff]) + static_cast<double>(sR[pk[k] >> 16]);
+                    vq[e] = static_cast<float>(__builtin_fma(cd, 0.25, pab[k]));
+                }
+                if (CERT) { ck = min(ck, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ck)); }
+                if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
+            }
+            {
+                const unsigned r = (unsigned)ri - cb;
+                if ((unsigned)ri >= cb && (unsigned)ri < ce && ((r >> 2) & (NT - 1)) == tl)
+                    st_off<float>(orowp, (unsigned)ri * 4u, diag);
+            }
+            if (CERT) { if (ck < p.cert_thresh) p.cert_out[ri] = 1; }     // plain store: the words only ever go 0 -> 1
+            wfin_b = w + 1;
+            wfin_e = (nextB == p.n_prev) ? we : w + 1;
+        }
+        // children without a B source (dragged or one-parent rows): finish from pab alone
+        for (int wf = wfin_b; wf < wfin_e; ++wf) {
+            unsigned tlf = tl;
+            asm volatile("" : "+v"(tlf));
+            __builtin_assume(tlf < NT);
+            const int4 df = desc[wf];
+            const bool new_f = df.w < 0;
+            float *orowp = p.out + (long long)df.y * p.ld;
+            const double sc = new_f ? 1.0 : 2.0;          // pab carries 1/4; a dragged row weighs 1, not 1/2
+            const unsigned row_bytes = (unsigned)p.ld * 4u;
+            unsigned ckf = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned jq = cb + q * 4 * NT + tlf * 4;
+                f4_t vq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = static_cast<float>(pab[4 * q + e] * sc);
+                    vq[e] = (jq + e == (unsigned)df.x && new_f) ? 0.5f : v;
+                }
+                if (CERT) { ckf = min(ckf, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ckf)); }
+                if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
+            }
+            if (CERT) { if (ckf < p.cert_thresh) p.cert_out[df.x] = 1; }
+        }
+
+        // ---- advance the stage state ----
+        if (nextB != p.n_prev) {
+            w = stage_is_a ? wb : w + 1;
+            stage_is_a = false;
+        } else {
+            if (!have_next) break;
+            it = next_item;
+            g = gn; gk = gkn;
+            chunk = it - gk * p.n_chunks;
+            wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
+            w = wb;
+            stage_is_a = true;
+            cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
         }
     }
-    for (long long j = p.n + tid; j < p.ld; j += nt) r.orowp[j] = 0.f;
+}
+
+// Splits the sibling groups of one SPLIT launch by certificate, on the device: a group is certified
+// when the A row and the B row of every child carry the certificate (cert_prev == 0).  Certified
+// group indices are appended to list0, the others to list1 (either may be nullptr); cnt[0] / cnt[1]
+// receive their numbers.  The 256 groups of a block stay contiguous and in order (block-level
+// scan, one atomic per block and list), so the planner's reuse order survives up to the order in
+// which the blocks arrive.  `span` != nullptr: the row range that decides is span[g] (the
+// grouping-exact kernel walks halves of the groups of 8 and must own exactly the rows the other
+// kernel does not).
+__global__ void __launch_bounds__(256)
+group_split_kernel(const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int2 *__restrict__ span, int n_groups,
+                   const int *__restrict__ cert_prev, int *__restrict__ list0, int *__restrict__ list1, int *__restrict__ cnt)
+{
+    __shared__ int wsum[4][2];
+    __shared__ int base[2];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    const bool live = g < n_groups;
+    if (live) {
+        int wb = grp[g].x, we = grp[g + 1].x;
+        if (span) { wb = span[g].x; we = span[g].y; }
+        bad = cert_prev[grp[g].y];                        // "none" (index n_prev) is never flagged
+        for (int w = wb; w < we; ++w) bad |= cert_prev[desc[w].z];
+    }
+    const unsigned long long m0 = __ballot(live && bad == 0), m1 = __ballot(live && bad != 0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int r0 = __popcll(m0 & below), r1 = __popcll(m1 & below);
+    if (lane == 0) { wsum[wv][0] = __popcll(m0); wsum[wv][1] = __popcll(m1); }
+    __syncthreads();
+    int o0 = 0, o1 = 0, t0 = 0, t1 = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < wv) { o0 += wsum[k][0]; o1 += wsum[k][1]; }
+        t0 += wsum[k][0]; t1 += wsum[k][1];
+    }
+    if (threadIdx.x == 0) { base[0] = atomicAdd(&cnt[0], t0); base[1] = atomicAdd(&cnt[1], t1); }
+    __syncthreads();
+    if (live) {
+        if (bad == 0) { if (list0) list0[base[0] + o0 + r0] = g; }
+        else          { if (list1) list1[base[1] + o1 + r1] = g; }
+    }
+}
+
+// ---- WIDE levels: streaming passes over level matrices whose rows do not fit in LDS ------------
+// The cut is stored [dragged members by previous position..., new members by rank...], so
+//   dragged x dragged  out[i][j] = Psi[s_i][s_j]                      s increasing: a stream compaction
+//   new x dragged      out[x][j] = RN32((Psi[f_x][s_j] + Psi[m_x][s_j]) / 2)   (src/compute.jl:111-126:
+//                      0. + h(Psi[s_j, f_x]) + h(Psi[s_j, m_x]); a two-term Float64 sum, order-free)
+//   dragged x new      the transpose of new x dragged (every level matrix is bit-symmetric)
+//   new x new          a FULL / SPLIT level step of its own on Psi_P = Psi[parents][parents]
+// rows_compact_kernel does the first two and extracts Psi_P: for work row w,
+//   out[orow(w)][k] = RN32((Psi[A(w)][idx[k]] + Psi[B(w)][idx[k]]) * scale(w)),  k < m,
+// with idx ascending (coalescing survives: consecutive lanes read nearly consecutive floats) and
+// B = none for single-source rows (uniform branch: the zero row is not streamed).
+// rowdesc[w] = (A, B, output row, scale exponent: 0 -> x1, -1 -> x1/2).
+__global__ void __launch_bounds__(256)
+rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, const int4 *__restrict__ rowdesc,
+                    const int *__restrict__ idx, int m, float *__restrict__ out, long long ld_out, int *__restrict__ cert_out,
+                    unsigned cert_thresh)
+{
+    const int4 d = rowdesc[blockIdx.x];
+    const float *ra = psi + (long long)d.x * ld_prev;
+    const float *rb = psi + (long long)d.y * ld_prev;
+    float *o = out + (long long)d.z * ld_out;
+    const double sc = d.w == 0 ? 1.0 : 0.5;
+    const int k0 = blockIdx.y * 2048;
+    const int k1 = min(k0 + 2048, m);
+    unsigned ck = 0xffffffffu;
+    if (d.y == none) {
+        for (int k = k0 + threadIdx.x; k < k1; k += 256) {
+            const float v = static_cast<float>(static_cast<double>(ra[idx[k]]) * sc);
+            ck = min(ck, cert_key(v));
+            __builtin_nontemporal_store(v, o + k);
+        }
+    } else {
+        for (int k = k0 + threadIdx.x; k < k1; k += 256) {
+            const int q = idx[k];
+            const float v = static_cast<float>((static_cast<double>(ra[q]) + static_cast<double>(rb[q])) * sc);
+            ck = min(ck, cert_key(v));
+            __builtin_nontemporal_store(v, o + k);
+        }
+    }
+    if (cert_out && ck < cert_thresh) cert_out[d.z] = 1;
+}
+
+// dst[c][dst_col0 + r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS, both sides
+// coalesced): the dragged x new block from the new x dragged block.  Flags the certificate of every
+// destination row that receives an uncertified value.
+__global__ void __launch_bounds__(256)
+transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows, int cols, float *__restrict__ dst,
+                       long long ld_dst, int dst_col0, int *__restrict__ cert_out, unsigned cert_thresh)
+{
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) {
+            const float v = tile[tx][k];
+            dst[(long long)c * ld_dst + dst_col0 + r] = v;
+            if (cert_out && cert_key(v) < cert_thresh) cert_out[c] = 1;
+        }
+    }
+}
+
+// dst[dst_row0 + r][dst_col0 + c] = src[r][c] for r < rows, c < cols (the new x new block computed
+// by the sub-step into its own buffer)
+__global__ void __launch_bounds__(256)
+copy_block_kernel(const float *__restrict__ src, long long ld_src, int rows, int cols, float *__restrict__ dst, long long ld_dst,
+                  int dst_row0, int dst_col0)
+{
+    const int r = blockIdx.x;                          // rows on x: grid.y is limited to 65535
+    if (r >= rows) return;
+    const float *s_ = src + (long long)r * ld_src;
+    float *d_ = dst + (long long)(dst_row0 + r) * ld_dst + dst_col0;
+    for (int c = blockIdx.y * 1024 + threadIdx.x; c < min(cols, (int)(blockIdx.y + 1) * 1024); c += 256) d_[c] = s_[c];
+}
+
+// zero padding of a level matrix: columns [n, ld) of rows 0..n-1 and the whole "none" row n
+__global__ void __launch_bounds__(256) pad_zero_kernel(float *__restrict__ m, long long ld, int n)
+{
+    const int r = blockIdx.x;
+    float *row = m + (long long)r * ld;
+    for (long long j = (r < n ? n : 0) + threadIdx.x; j < ld; j += 256) row[j] = 0.f;
 }
 
 __global__ void level_naive_kernel(const LevelArgs p)
@@ -618,8 +937,66 @@ __global__ void level_naive_kernel(const LevelArgs p)
             const double sc = (oi < 0 ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
             v = combine(rowA[Aj], rowA[Bj], rowB[Aj], rowB[Bj], (oi & kOrdMask) > (oj & kOrdMask), sc);
         }
+        if (p.cert_out && cert_key(v) < p.cert_thresh) p.cert_out[i] = 1;
     }
     p.out[orow * p.ld + j] = v;
+}
+
+// ---- Float64 storage (opts flag GENPHI_FLAG_STORAGE_F64) -----------------------------------------
+// The pairwise recursion of the reference, phi(i::Individual, j::Individual) (src/compute.jl:66-95),
+// and gen.f built on it (:500-511) work in Float64 throughout and never round to Float32 between
+// generations.  The same level sweep with Float64 level matrices reproduces them: every kinship
+// is a dyadic rational, exactly representable in Float64 while the pedigree is less than ~26
+// generations deep (then the sweep and the recursion are bit-identical whatever their order of
+// operations), and within a few ulp (<< 1e-12) beyond.  One thread per entry, four global gathers;
+// meant for the small proband sets of gen.f / pairwise queries, not for throughput.
+//   colmap: member index of output column j (the last level is delivered in proband order), or nullptr
+__global__ void level_naive64_kernel(const double *__restrict__ psi, long long ld_prev, int n_prev, double *__restrict__ out,
+                                     long long ld, int n, const int *__restrict__ srcA, const int *__restrict__ srcB,
+                                     const int *__restrict__ ord, const int *__restrict__ rows, const int *__restrict__ out_rows,
+                                     const int *__restrict__ colmap, int n_cols)
+{
+    const int w = blockIdx.x;
+    const long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    const int i = rows ? rows[w] : w;
+    const long long orow = out_rows ? out_rows[w] : i;
+    double v = 0.0;
+    if (j < n_cols) {
+        const int jm = colmap ? colmap[j] : static_cast<int>(j);
+        const int Ai = srcA[i], Bi = srcB[i], oi = ord[i];
+        const int Aj = srcA[jm], Bj = srcB[jm], oj = ord[jm];
+        const double *rowA = psi + (long long)Ai * ld_prev;
+        const double *rowB = psi + (long long)Bi * ld_prev;
+        if (jm == i && oi < 0) {
+            v = 0.5 + 0.5 * rowA[Bi];
+        } else {
+            const double sc = (oi < 0 ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
+            const double a = rowA[Aj], b = rowA[Bj], c = rowB[Aj], d = rowB[Bj];
+            const bool i_hi = (oi & kOrdMask) > (oj & kOrdMask);
+            const double x = i_hi ? b : c, y = i_hi ? c : b;
+            v = ((a + x) + (y + d)) * sc;
+        }
+    }
+    (void)n_prev; (void)n;
+    out[orow * ld + j] = v;
+}
+
+__global__ void half_identity64_kernel(double *m, long long ld, int n, const int *out_rows, int n_rows, const int *colmap)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    // row k of the output is member (colmap ? colmap[k'] ...): used only for the all-founders case,
+    // where every member is a proband: diagonal of the delivered matrix
+    (void)colmap; (void)out_rows; (void)n;
+    m[(long long)k * ld + k] = 0.5;
+}
+
+__global__ void gather_entries64_kernel(const double *__restrict__ m, const long long *__restrict__ off, long long n,
+                                        double *__restrict__ out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = m[off[k]];
 }
 
 // ---- SMALL: a run of consecutive level steps whose cuts have <= kSmallMax members, fused -----
@@ -637,7 +1014,8 @@ struct SmallStep {
 
 __global__ void __launch_bounds__(1024)
 levels_small_kernel(const SmallStep *__restrict__ steps, int n_run, const float *__restrict__ in, long long ld_in,
-                    int in_is_half_identity, float *__restrict__ out, long long ld_out)
+                    int in_is_half_identity, float *__restrict__ out, long long ld_out, int *__restrict__ cert_out,
+                    unsigned cert_thresh)
 {
     extern __shared__ float lds[];
     constexpr int P = kSmallPitch;
@@ -681,7 +1059,9 @@ levels_small_kernel(const SmallStep *__restrict__ steps, int n_run, const float 
     const int n = steps[n_run - 1].n;
     for (long long idx = tid; idx < (long long)(n + 1) * ld_out; idx += nt) {
         const int i = static_cast<int>(idx / ld_out), j = static_cast<int>(idx - (long long)i * ld_out);
-        out[idx] = (j <= n) ? cur[i * P + j] : 0.f;
+        const float v = (j <= n) ? cur[i * P + j] : 0.f;
+        out[idx] = v;
+        if (cert_out && i < n && cert_key(v) < cert_thresh) cert_out[i] = 1;      // exactness certificate of row i
     }
 }
 
@@ -780,7 +1160,8 @@ __global__ void row_sums_kernel(const float *m, long long ld, int n, int row_beg
     if (threadIdx.x == 0) { row_sum[k] = part[0]; diag[k] = static_cast<double>(row[row_begin + k]); }
 }
 
-// out[k][c] = in[k][perm[c]]  (rows were already delivered in proband order by the level kernel)
+// out[k][c] = in[perm[row_begin + k]][perm[c]]: the last level of a WIDE step, computed in storage
+// order, delivered in proband order
 // A per-element global gather runs at ~0.4 TB/s (one cache line per lane).  Here a workgroup
 // owns (row, column chunk): it keeps the chunk's perm words and output values in registers,
 // stages the source row through LDS one segment at a time (16-byte coalesced loads), picks the
@@ -788,7 +1169,7 @@ __global__ void row_sums_kernel(const float *m, long long ld, int n, int row_beg
 template <int CPT>
 __global__ void __launch_bounds__(1024)
 colperm_kernel(const float *__restrict__ in, float *__restrict__ out, long long ld, int n, const int *__restrict__ perm,
-               int n_chunks, int seg_floats, int n_segs)
+               int n_chunks, int seg_floats, int n_segs, int row_begin)
 {
     extern __shared__ float lds[];
     static_assert(CPT % 4 == 0, "columns are handled in quads");
@@ -796,7 +1177,7 @@ colperm_kernel(const float *__restrict__ in, float *__restrict__ out, long long 
     const int row = blockIdx.x / n_chunks, chunk = blockIdx.x - row * n_chunks;
     const int tid = threadIdx.x;
     const long long c0 = (long long)chunk * CPT * 1024;
-    const float *src = in + (long long)row * ld;
+    const float *src = in + (long long)perm[row_begin + row] * ld;      // rows too are in storage order
     int pidx[CPT];
     float val[CPT];
 #pragma unroll
@@ -851,37 +1232,87 @@ constexpr size_t kTailPadFloats = 64 * 1024;
 // pk / ord are padded so that the unrolled per-thread column loops need no clamp
 constexpr size_t kIdxPad = 32 * 1024;
 
-struct DeviceStep {
-    int *srcA = nullptr, *srcB = nullptr, *ord = nullptr, *work = nullptr, *b_rel = nullptr;
-    unsigned *pk = nullptr;
-    Segment *segs = nullptr;
-    int4 *desc = nullptr;      // SPLIT: per work row (storage row, output row, B source, ord word)
-    int2 *grp = nullptr;       // SPLIT: per sibling group (first work row, A source) + terminator
-    int n_groups = 0;
+// Sibling groups of a SPLIT work list (rows sorted by (A source, B source); "no B" = n_prev sorts
+// last): runs of equal A source, capped.  Two nested lists over the same row descriptors:
+//   grp   : groups of <= 8 children, walked by level_split_fast_kernel (no per-child state)
+//   grp_s : what level_split_kernel walks.  Where it needs rank masks (cut not in rank order) it
+//           keeps one 32-bit mask per child in 4 VGPRs, so its groups are the halves of the groups
+//           of 8; span_s[g] = work-row range of the enclosing group of 8, whose certificate decides
+//           which kernel owns the rows.  Otherwise grp_s is grp itself (span_s empty).
+struct GroupLists {
+    std::vector<int4> desc;    // per work row: (storage row, output row, B source, ord word)
+    std::vector<int2> grp;     // (first work row, A source) + terminator
+    std::vector<int2> grp_s, span_s;
+};
+struct DeviceGroups {
+    int4 *desc = nullptr;
+    int2 *grp = nullptr, *grp_s = nullptr, *span_s = nullptr;
+    int n_groups = 0, n_groups_s = 0;
 };
 
-// Sibling groups of a work list (rows sorted by (A source, B source); "no B" = n_prev sorts last):
-// runs of equal A source.  out_rows == nullptr => output row = storage row.
-static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows,
-                         std::vector<int4> &desc, std::vector<int2> &grp)
+struct DeviceStep {
+    int *srcA = nullptr, *srcB = nullptr, *ord = nullptr, *work = nullptr;
+    unsigned *pk = nullptr;
+    DeviceGroups groups;       // SPLIT
+    // WIDE: row descriptors of rows_compact_kernel for the cut's own rows (A, B, row, scale exponent)
+    // and for the parent rows of Psi_P; the parents' positions; the new rows as a work list
+    int4 *rowdesc = nullptr, *pardesc = nullptr;
+    int *parents = nullptr, *newrows = nullptr;
+    int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
+};
+
+static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl)
 {
-    desc.resize(n_rows);
-    grp.clear();
-    int lastA = -1;
+    gl.desc.resize(n_rows);
+    gl.grp.clear(); gl.grp_s.clear(); gl.span_s.clear();
     // groups are capped: a workgroup walks a group's children one after the other, so one huge
     // group (e.g. all parentless rows share "no A source") would be a serial tail
     static const int env_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 8;
-    // the generic (rank-word) kernel variant keeps one bitmask per child: at most 4 children
-    const int max_group = s.pos_ord ? env_group : std::min(env_group, 4);
+    const int cap = env_group;
+    const int cap_s = s.pos_ord ? cap : std::min(cap, 4);
+    int lastA = -1;
     for (int w = 0; w < n_rows; ++w) {
         const int i = rows[w];
-        desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);
-        if (w == 0 || s.srcA[i] != lastA || w - grp.back().x >= max_group) {
-            grp.push_back(make_int2(w, s.srcA[i]));
+        gl.desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);
+        if (w == 0 || s.srcA[i] != lastA || w - gl.grp.back().x >= cap) {
+            gl.grp.push_back(make_int2(w, s.srcA[i]));
             lastA = s.srcA[i];
         }
     }
-    grp.push_back(make_int2(n_rows, 0));
+    gl.grp.push_back(make_int2(n_rows, 0));
+    if (cap_s != cap) {
+        const int ng = static_cast<int>(gl.grp.size()) - 1;
+        for (int g = 0; g < ng; ++g) {
+            const int wb = gl.grp[g].x, we = gl.grp[g + 1].x;
+            for (int w = wb; w < we; w += cap_s) {
+                gl.grp_s.push_back(make_int2(w, gl.grp[g].y));
+                gl.span_s.push_back(make_int2(wb, we));
+            }
+        }
+        gl.grp_s.push_back(make_int2(n_rows, 0));
+    }
+}
+
+static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+static size_t groups_bytes(const GroupLists &gl)
+{
+    return al256(gl.desc.size() * sizeof(int4)) + al256(gl.grp.size() * sizeof(int2)) + al256(gl.grp_s.size() * sizeof(int2)) +
+           al256(gl.span_s.size() * sizeof(int2));
+}
+// put(src, bytes) copies into the host image of a device blob and returns the device address
+template <class Put>
+static void put_groups(const GroupLists &gl, DeviceGroups &d, Put &&put)
+{
+    d.desc = reinterpret_cast<int4 *>(put(gl.desc.data(), gl.desc.size() * sizeof(int4)));
+    d.grp = reinterpret_cast<int2 *>(put(gl.grp.data(), gl.grp.size() * sizeof(int2)));
+    d.n_groups = static_cast<int>(gl.grp.size()) - 1;
+    if (!gl.grp_s.empty()) {
+        d.grp_s = reinterpret_cast<int2 *>(put(gl.grp_s.data(), gl.grp_s.size() * sizeof(int2)));
+        d.span_s = reinterpret_cast<int2 *>(put(gl.span_s.data(), gl.span_s.size() * sizeof(int2)));
+        d.n_groups_s = static_cast<int>(gl.grp_s.size()) - 1;
+    } else {
+        d.grp_s = d.grp; d.span_s = nullptr; d.n_groups_s = d.n_groups;
+    }
 }
 
 struct genphi_plan {
@@ -894,9 +1325,15 @@ struct genphi_plan {
     hipStream_t stream = nullptr;
     char *idx_blob = nullptr;
     std::vector<DeviceStep> dsteps;
+    std::vector<const LevelStep *> nn_steps;     // new x new sub-steps of the WIDE steps (owned by the plan's steps)
+    std::vector<DeviceStep> nn_dsteps;
+    float *psi_p = nullptr, *nn_out = nullptr;   // WIDE: compacted parent matrix, the sub-step's result
+    int *d_cert_p = nullptr;                     // certificates of the rows of psi_p
+    size_t cert_p_words = 0;
     int *d_final_perm = nullptr;
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
-    int *d_queues = nullptr;        // 8 work-queue counters per level step
+    int *d_queues = nullptr;        // 16 work-queue counters per slot (a level step or a new x new sub-step)
+    size_t n_slots = 0;
     SmallStep *d_small = nullptr;   // one entry per level step (levels_small_kernel)
     hipGraphExec_t graph_exec = nullptr;   // captured sweep (see genphi_compute_device)
     // key = (kernel, r0, r1, need_perm, alloc_gen).  A captured graph bakes raw device pointers into
@@ -907,20 +1344,31 @@ struct genphi_plan {
     char *scratch = nullptr;               // genphi_result_sums / _entries staging (grown on demand)
     size_t scratch_bytes = 0;
     bool eager_valid = false;
-    int4 *d_shard_desc = nullptr;
-    int2 *d_shard_grp = nullptr;
+    DeviceGroups shard_groups;      // SPLIT lists of the last step restricted to the shard (arrays inside d_shard_blob)
+    char *d_shard_blob = nullptr;
+    size_t shard_blob_bytes = 0;
+    // exactness certificates: one word per row of every level matrix (cert_off[c] = first word of
+    // cut c), the per-launch group flags and [certified, other] group counts per step
+    int *d_cert = nullptr, *d_glist = nullptr, *d_gcnt = nullptr;
+    std::vector<size_t> cert_off;
+    size_t cert_words = 0;
     // Row shards: an upper level only needs the rows its shard's last-level rows descend from
     // (~80 % of a cut at 8 shards of cfg4, 55-72 % in the two levels below the last).  Per
     // intermediate step: restricted work list (+ SPLIT descriptors) of the current shard.
-    struct ShardStep { int *rows = nullptr; int4 *desc = nullptr; int2 *grp = nullptr; int n_rows = 0, n_groups = 0; };
+    struct ShardStep { int *rows = nullptr; DeviceGroups groups; int n_rows = 0; };
     std::vector<ShardStep> sh_steps;
     char *sh_blob = nullptr;
     bool sh_valid = false;
-    int shard_groups = 0;
     int64_t shard_cap = 0, shard_r0 = -1, shard_r1 = -1;
     float *buf[2] = {nullptr, nullptr};
     size_t buf_floats[2] = {0, 0};
     float *result = nullptr, *final_tmp = nullptr;
+    // Float64-storage sweeps (gen.f, pairwise phi): own level matrices and result
+    double *buf64[2] = {nullptr, nullptr}, *result64 = nullptr;
+    size_t buf64_doubles[2] = {0, 0}, result64_doubles = 0;
+    int *d_perm_rows = nullptr;                  // storage member of each resident proband row (f64 sweeps)
+    size_t perm_rows_cap = 0;
+    bool res_f64 = false;                        // the resident result is the Float64 one
     size_t result_floats = 0, final_tmp_floats = 0;
     int64_t res_ld = 0, res_row_begin = 0, res_n_rows = 0;
     std::vector<hipEvent_t> events;
@@ -950,12 +1398,18 @@ static void free_device(genphi_plan *p)
     drop_graph(p);
     auto release = [](auto *&ptr) { if (ptr) (void)hipFree(ptr); ptr = nullptr; };
     release(p->idx_blob);
-    release(p->d_shard_rows); release(p->d_shard_out_rows); release(p->d_shard_desc); release(p->d_shard_grp);
+    release(p->d_shard_rows); release(p->d_shard_out_rows); release(p->d_shard_blob);
+    release(p->d_cert); release(p->d_glist); release(p->d_gcnt);
+    p->shard_groups = DeviceGroups(); p->shard_blob_bytes = 0; p->cert_off.clear(); p->cert_words = 0;
     release(p->d_queues); release(p->d_small); release(p->sh_blob); release(p->scratch);
     release(p->buf[0]); release(p->buf[1]); release(p->result); release(p->final_tmp);
+    release(p->psi_p); release(p->nn_out); release(p->d_cert_p);
+    release(p->buf64[0]); release(p->buf64[1]); release(p->result64); release(p->d_perm_rows);
+    p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
+    p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
     p->d_final_perm = nullptr;                       // lived inside idx_blob
     p->dsteps.clear(); p->sh_steps.clear();
-    p->sh_valid = false; p->shard_groups = 0;
+    p->sh_valid = false;
     p->shard_cap = 0; p->shard_r0 = p->shard_r1 = -1;
     p->buf_floats[0] = p->buf_floats[1] = 0;
     p->result_floats = p->final_tmp_floats = 0; p->scratch_bytes = 0;
@@ -1018,7 +1472,23 @@ int genphi_plan_step_mode(const genphi_plan *plan, int32_t step)
     if (!plan || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size())) return -1;
     return plan->plan.steps[step].mode;
 }
+int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info)
+{
+    if (!plan || !info || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size()))
+        return fail(GENPHI_ERR_ARG, "genphi_plan_step_info: bad argument");
+    const LevelStep &s = plan->plan.steps[step];
+    info[0] = s.mode; info[1] = s.n_dragged; info[2] = static_cast<int64_t>(s.parents.size());
+    info[3] = s.mode != genphi::kModeWide ? -1 : (s.nn.empty() ? 3 : s.nn[0].mode);
+    return GENPHI_OK;
+}
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
+
+int genphi_plan_release_device(genphi_plan *plan)
+{
+    if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    free_device(plan);
+    return GENPHI_OK;
+}
 
 void genphi_plan_destroy(genphi_plan *plan)
 {
@@ -1054,9 +1524,23 @@ static int upload_plan(genphi_plan *p, int device)
     const Plan &pl = p->plan;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t total = 256;
-    for (const LevelStep &s : pl.steps) {
-        total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int)) + al(s.b_rel.size() * sizeof(int)) +
-                 al(s.segs.size() * sizeof(Segment)) + al(s.n * sizeof(int4)) + al((s.n + 1) * sizeof(int2));
+    // every step to upload: the plan's steps, then the new x new sub-steps of the WIDE ones
+    p->nn_steps.clear();
+    for (const LevelStep &s : pl.steps)
+        if (s.mode == genphi::kModeWide && !s.nn.empty()) p->nn_steps.push_back(&s.nn[0]);
+    const size_t n_main = pl.steps.size(), n_all = n_main + p->nn_steps.size();
+    auto step_at = [&](size_t k) -> const LevelStep & { return k < n_main ? pl.steps[k] : *p->nn_steps[k - n_main]; };
+    std::vector<GroupLists> step_groups(n_all);
+    for (size_t k = 0; k < n_all; ++k) {
+        const LevelStep &s = step_at(k);
+        total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
+        if (s.mode == genphi::kModeSplit) {
+            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.n), step_groups[k]);
+            total += groups_bytes(step_groups[k]);
+        }
+        if (s.mode == genphi::kModeWide)
+            total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
+                     al((s.n - s.n_dragged) * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
@@ -1068,36 +1552,58 @@ static int upload_plan(genphi_plan *p, int device)
         off += al(bytes + pad_bytes);
         return d;
     };
-    p->dsteps.resize(pl.steps.size());
-    for (size_t k = 0; k < pl.steps.size(); ++k) {
-        const LevelStep &s = pl.steps[k];
-        DeviceStep &d = p->dsteps[k];
+    p->dsteps.assign(n_main, DeviceStep());
+    p->nn_dsteps.assign(n_all - n_main, DeviceStep());
+    int nn_next = 0;
+    for (size_t k = 0; k < n_all; ++k) {
+        const LevelStep &s = step_at(k);
+        DeviceStep &d = k < n_main ? p->dsteps[k] : p->nn_dsteps[k - n_main];
         d.srcA = reinterpret_cast<int *>(put(s.srcA.data(), s.n * sizeof(int)));
         d.srcB = reinterpret_cast<int *>(put(s.srcB.data(), s.n * sizeof(int)));
         d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int), kIdxPad * sizeof(int)));
-        d.work = reinterpret_cast<int *>(put(s.work.data(), s.n * sizeof(int)));
+        d.work = reinterpret_cast<int *>(put(s.work.data(), s.work.size() * sizeof(int)));
         d.pk = reinterpret_cast<unsigned *>(put(s.pk.data(), s.pk.size() * sizeof(unsigned), kIdxPad * sizeof(unsigned)));
         if (!s.pk.empty()) {      // padding entries point both sources at the zero column
             unsigned *hp = reinterpret_cast<unsigned *>(host.data() + (reinterpret_cast<char *>(d.pk) - p->idx_blob));
             const unsigned zero_pk = static_cast<unsigned>(s.n_prev) | (static_cast<unsigned>(s.n_prev) << 16);
-            for (size_t k = s.pk.size(); k < s.pk.size() + kIdxPad; ++k) hp[k] = zero_pk;
+            for (size_t k2 = s.pk.size(); k2 < s.pk.size() + kIdxPad; ++k2) hp[k2] = zero_pk;
         }
-        d.b_rel = reinterpret_cast<int *>(put(s.b_rel.data(), s.b_rel.size() * sizeof(int)));
-        d.segs = reinterpret_cast<Segment *>(put(s.segs.data(), s.segs.size() * sizeof(Segment)));
-        if (s.mode == genphi::kModeSplit) {
-            std::vector<int4> desc;
-            std::vector<int2> grp;
-            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.n), desc, grp);
-            d.n_groups = static_cast<int>(grp.size()) - 1;
-            d.desc = reinterpret_cast<int4 *>(put(desc.data(), desc.size() * sizeof(int4)));
-            d.grp = reinterpret_cast<int2 *>(put(grp.data(), grp.size() * sizeof(int2)));
+        if (s.mode == genphi::kModeSplit) put_groups(step_groups[k], d.groups, put);
+        if (s.mode == genphi::kModeWide) {
+            const int none = static_cast<int>(s.n_prev);
+            std::vector<int4> rd(s.n), pd(s.parents.size());
+            std::vector<int> nr(s.n - s.n_dragged);
+            for (int64_t r = 0; r < s.n; ++r)              // dragged: weight 1; new: weight 1/2 (columns here are dragged: weight 1)
+                rd[r] = make_int4(s.srcA[r], s.srcB[r], static_cast<int>(r), s.ord[r] < 0 ? -1 : 0);
+            for (size_t u = 0; u < s.parents.size(); ++u) pd[u] = make_int4(s.parents[u], none, static_cast<int>(u), 0);
+            for (size_t r = 0; r < nr.size(); ++r) nr[r] = static_cast<int>(s.n_dragged + r);
+            d.rowdesc = reinterpret_cast<int4 *>(put(rd.data(), rd.size() * sizeof(int4)));
+            d.pardesc = reinterpret_cast<int4 *>(put(pd.data(), pd.size() * sizeof(int4)));
+            d.parents = reinterpret_cast<int *>(put(s.parents.data(), s.parents.size() * sizeof(int)));
+            d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
+            if (!s.nn.empty()) d.nn = nn_next++;
         }
     }
     p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
     HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
 
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_queues), (pl.steps.size() + 1) * 8 * sizeof(int)));
+    const size_t n_slots = n_all + 1;                    // queue / counter slots: one per (sub-)step
+    p->n_slots = n_slots;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_queues), n_slots * 16 * sizeof(int)));
+    {   // certificates: words [cert_off[c], cert_off[c] + n_c] belong to cut c (incl. its "none" row)
+        p->cert_off.assign(pl.n_levels + 1, 0);
+        size_t w = 0;
+        for (int c = 0; c < pl.n_levels; ++c) {
+            p->cert_off[c] = w;
+            w += static_cast<size_t>(pl.cut_sizes[c]) + 1;
+        }
+        p->cert_off[pl.n_levels] = w;
+        p->cert_words = w;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cert), std::max<size_t>(w, 1) * sizeof(int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gcnt), n_slots * 4 * sizeof(int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_glist), 2 * ((static_cast<size_t>(pl.max_cut) + 64) / 64 * 64) * sizeof(int)));
+    }
     {
         std::vector<SmallStep> sm(pl.steps.size() + 1);
         for (size_t k = 0; k < pl.steps.size(); ++k)
@@ -1119,6 +1625,23 @@ static int upload_plan(genphi_plan *p, int device)
             HIP_TRY(hipMemsetAsync(p->buf[b], 0, need[b] * sizeof(float), p->stream));
         }
         p->buf_floats[b] = need[b];
+    }
+    // WIDE steps: the compacted parent matrix, the sub-step's result, the parent rows' certificates
+    {
+        size_t need_p = 0, need_o = 0, need_c = 0;
+        for (const LevelStep *nn : p->nn_steps) {
+            need_p = std::max(need_p, static_cast<size_t>((nn->n_prev + 1) * nn->ld_prev) + kTailPadFloats);
+            need_o = std::max(need_o, static_cast<size_t>((nn->n + 1) * nn->ld) + kTailPadFloats);
+            need_c = std::max(need_c, static_cast<size_t>(nn->n_prev) + 1);
+        }
+        if (need_p) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(p->psi_p, 0, need_p * sizeof(float), p->stream));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->nn_out), need_o * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(p->nn_out, 0, need_o * sizeof(float), p->stream));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cert_p), need_c * sizeof(int)));
+            p->cert_p_words = need_c;
+        }
     }
     return GENPHI_OK;
 }
@@ -1183,17 +1706,61 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
                                const int4 *desc, const int2 *grp, int *queue)
 {
 #define GENPHI_T(C, S) if (cpt <= C && stg == S) return launch_split_inst<C, S, O>(grid, lds, stream, a, desc, grp, queue)
+#ifdef GENPHI_MIN_INST
+    GENPHI_T(16, 2); GENPHI_T(20, 8);
+#else
     GENPHI_T(8, 2); GENPHI_T(16, 2); GENPHI_T(24, 2);
     GENPHI_T(8, 4); GENPHI_T(16, 4); GENPHI_T(24, 4);
     GENPHI_T(8, 6); GENPHI_T(16, 6); GENPHI_T(20, 6); GENPHI_T(24, 6);
-    if constexpr (O) { GENPHI_T(28, 6); }
-    GENPHI_T(8, 7); GENPHI_T(16, 7); GENPHI_T(20, 7); GENPHI_T(24, 7);
-    if constexpr (O) { GENPHI_T(28, 7); }
+    GENPHI_T(8, 7); GENPHI_T(16, 7); GENPHI_T(20, 7); if constexpr (O) { GENPHI_T(24, 7); }
     GENPHI_T(8, 8); GENPHI_T(16, 8); GENPHI_T(20, 8);
-    if constexpr (O) { GENPHI_T(24, 8); }
-    if constexpr (O) { GENPHI_T(24, 8); }
     GENPHI_T(8, 9); GENPHI_T(16, 9);
+#endif
 #undef GENPHI_T
+    return hipErrorInvalidValue;
+}
+
+// certified-rows kernel: 1024-thread workgroups (4 waves per SIMD, 128 VGPRs) or 512-thread ones
+// (2 waves per SIMD, 256 VGPRs: the per-thread overhead is paid half as often, so a workgroup
+// holds ~25 % more columns -- 4 column chunks instead of 5 for the 1e5-wide final level of cfg4)
+template <int NT, int C, int S, bool CERT>
+static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
+                                   const int2 *grp, int *queue)
+{
+    hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, queue);
+    return hipGetLastError();
+}
+
+// columns per thread the instantiations of the certified-rows kernel afford without spilling
+// (checked with -Rpass-analysis=kernel-resource-usage: 0 scratch in every one)
+static int fast_max_cpt(int nt, int stg)
+{
+    if (nt == 1024) return stg <= 4 ? 28 : (stg <= 8 ? 24 : 20);
+    return stg <= 12 ? 48 : (stg <= 16 ? 56 : 48);
+}
+
+template <bool CERT>
+static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
+                              const int4 *desc, const int2 *grp, int *queue)
+{
+#define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT>(grid, lds, stream, a, desc, grp, queue)
+#ifdef GENPHI_MIN_INST
+    GENPHI_F(1024, 16, 2); GENPHI_F(1024, 24, 8); GENPHI_F(512, 56, 16);
+#else
+    GENPHI_F(1024, 8, 2); GENPHI_F(1024, 16, 2); GENPHI_F(1024, 28, 2);
+    GENPHI_F(1024, 8, 4); GENPHI_F(1024, 16, 4); GENPHI_F(1024, 28, 4);
+    GENPHI_F(1024, 8, 6); GENPHI_F(1024, 16, 6); GENPHI_F(1024, 24, 6);
+    GENPHI_F(1024, 8, 7); GENPHI_F(1024, 16, 7); GENPHI_F(1024, 24, 7);
+    GENPHI_F(1024, 8, 8); GENPHI_F(1024, 16, 8); GENPHI_F(1024, 24, 8);
+    GENPHI_F(1024, 8, 9); GENPHI_F(1024, 20, 9);
+    GENPHI_F(512, 32, 12); GENPHI_F(512, 48, 12);
+    GENPHI_F(512, 32, 14); GENPHI_F(512, 56, 14);
+    GENPHI_F(512, 32, 16); GENPHI_F(512, 56, 16);
+    GENPHI_F(512, 32, 18); GENPHI_F(512, 48, 18);
+#endif
+#undef GENPHI_F
     return hipErrorInvalidValue;
 }
 
@@ -1212,23 +1779,64 @@ static int block_size_for(int64_t n)
 // (GENPHI_NO_IDENTITY: test hook, the regular kernels on a materialised 1/2 I)
 static bool identity_source(int step) { return step == 0 && std::getenv("GENPHI_NO_IDENTITY") == nullptr; }
 
-static int launch_level(genphi_plan *p, int step, const float *psi, float *out, const int *rows,
-                        const int *out_rows, int n_rows, int kernel, const int4 *desc, const int2 *grp, int n_groups)
+// item / n_chunks as a multiply-high: exact for item < 2^32 / n_chunks (items are < 2^31 and n_chunks
+// is a handful); n_chunks == 1 has no 32-bit magic number and is flagged by 0
+static unsigned chunk_magic_for(int n_chunks)
 {
-    const LevelStep &s = p->plan.steps[step];
-    const DeviceStep &d = p->dsteps[step];
+    return n_chunks <= 1 ? 0u : 0xffffffffu / static_cast<unsigned>(n_chunks) + 1u;
+}
+
+// bits(2^-27) - 1: entries below 2^-27 (other than 0) void a row's exactness certificate.  Test hook:
+// GENPHI_CERT_MIN_EXP = e in [-27, 0] raises the bound to 2^e (always safe: fewer rows certified),
+// which makes mixed certified / uncertified levels out of ordinary small pedigrees.
+static unsigned cert_threshold()
+{
+    const int min_exp = std::getenv("GENPHI_CERT_MIN_EXP") ? std::atoi(std::getenv("GENPHI_CERT_MIN_EXP")) : -27;
+    const int e = std::max(-27, std::min(0, min_exp));
+    return (static_cast<unsigned>(127 + e) << 23) - 1u;
+}
+
+// What a level launch works on: a step of the plan, or the new x new sub-step of a WIDE step.
+struct LevelCtx {
+    const LevelStep *s;
+    const DeviceStep *d;
+    int slot;                  // queue / counter slot (d_queues + 16 * slot, d_gcnt + 4 * slot)
+    const int *cert_prev;      // certificates of the source rows / of the rows written (nullptr: last level)
+    int *cert_out;
+    bool identity;             // the source matrix is Psi_1 = 1/2 I, never materialised
+    bool dbg;                  // GENPHI_WG_TIMES builds: record this launch
+};
+
+static LevelCtx main_ctx(genphi_plan *p, int step)
+{
+    LevelCtx c;
+    c.s = &p->plan.steps[step]; c.d = &p->dsteps[step]; c.slot = step;
+    c.cert_prev = p->d_cert + p->cert_off[step];
+    c.cert_out = p->d_cert + p->cert_off[step + 1];      // (the last level's have no reader: harmless)
+    c.identity = identity_source(step);
+    const char *e = std::getenv("GENPHI_DBG_STEP");                            // default: the last step
+    c.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step;
+    return c;
+}
+
+static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, float *out, const int *rows,
+                        const int *out_rows, int n_rows, int kernel, const DeviceGroups &dg)
+{
+    const LevelStep &s = *cx.s;
+    const DeviceStep &d = *cx.d;
+    const int step = cx.slot;
     LevelArgs a;
     a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld;
     a.n_prev = static_cast<int>(s.n_prev); a.n = static_cast<int>(s.n);
     a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.pk = d.pk;
     a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
-    a.segs = d.segs; a.b_rel = d.b_rel; a.n_segs = static_cast<int>(s.segs.size());
     a.lds_row = 0; a.chunk_cols = 0;
-    {   // which level step GENPHI_WG_TIMES builds record: GENPHI_DBG_STEP (default: the last one)
-        const char *e = std::getenv("GENPHI_DBG_STEP");
-        a.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step ? 1 : 0;
-    }
-    a.zero_row = (out_rows == nullptr && kernel != 1 && s.mode != genphi::kModeHalf) ? 1 : 0;
+    a.dbg = cx.dbg ? 1 : 0;
+    a.zero_row = (out_rows == nullptr && kernel != 1) ? 1 : 0;
+    a.cert_prev = cx.cert_prev;
+    a.cert_out = out_rows == nullptr ? cx.cert_out : nullptr;
+    a.glist = nullptr; a.gcnt = nullptr; a.chunk_magic = 0;
+    a.cert_thresh = cert_threshold();
     if (n_rows <= 0) {
         // nothing to compute (a row shard whose ancestors do not reach this level), but the next level
         // still reads this level's all-zero "none" row for its parentless members
@@ -1239,7 +1847,7 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
     if (kernel == 1) {
         dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
         hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
-    } else if (identity_source(step)) {
+    } else if (cx.identity) {
         hipLaunchKernelGGL(level_identity_kernel, dim3(static_cast<unsigned>(n_rows)), dim3(256), 0, p->stream, a);
         if (out_rows == nullptr)         // intermediate level: its all-zero "none" row
             HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
@@ -1256,44 +1864,233 @@ static int launch_level(genphi_plan *p, int step, const float *psi, float *out, 
         }
     } else if (s.mode == genphi::kModeSplit) {
         a.lds_row = lds_row;
-        constexpr int nt = 1024;
-        const int stg = (lds_row / 4 + nt - 1) / nt;                 // float4 per thread per staged row
+        const int per_row4 = lds_row / 4;                                // float4 per staged row
+        const int stg1k = (per_row4 + 1023) / 1024;
         // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
-        const int stg_inst = stg <= 2 ? 2 : (stg <= 4 ? 4 : (stg <= 6 ? 6 : (stg <= 7 ? 7 : (stg <= 8 ? 8 : 9))));
+        const int stg_inst = stg1k <= 2 ? 2 : (stg1k <= 4 ? 4 : (stg1k <= 6 ? 6 : (stg1k <= 7 ? 7 : (stg1k <= 8 ? 8 : 9))));
+        const bool no_fast = std::getenv("GENPHI_NO_FAST") != nullptr;          // test / A-B hook: grouping-exact kernel only
+        const bool certs = !no_fast && kernel == 0;
+        int *queue = p->d_queues + 16 * step;                                 // zeroed at the start of the sweep
+        int *gcnt = p->d_gcnt + 4 * step;
+        // geometry of the grouping-exact kernel (1024 threads)
+        constexpr int nt_s = 1024;
         // LDS must also absorb the unconditional over-write past the row's end
-        const size_t lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt * 16);
-        const size_t lds = lds_stage + 16 + (GENPHI_WG_TIMES ? 128 : 0);
-        a.slot_off = static_cast<int>(lds_stage / sizeof(float));
-        const int per_thread = static_cast<int>((s.ld + nt - 1) / nt);       // the padding columns [n, ld) are written too
+        const size_t lds_stage_s = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt_s * 16);
+        const size_t lds = lds_stage_s + 32 + (GENPHI_WG_TIMES ? 128 : 0);
+        const int per_thread = static_cast<int>((s.ld + nt_s - 1) / nt_s);     // the padding columns [n, ld) are written too
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
-        // (columns per thread an instantiation affords without spilling; (28, 6, pos) spills one
-        //  VGPR in stage A only and still wins over two chunks)
         int max_cpt;
-        if (s.pos_ord) max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 7 ? 28 : (stg_inst == 8 ? 24 : 16));
-        else           max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
-        if (const char *e = std::getenv("GENPHI_MAX_CPT")) {                  // tuning hook: smaller chunks
-            const int v = std::atoi(e);
-            if (v >= 4) max_cpt = std::min(max_cpt, v / 4 * 4);
-        }
+        if (s.pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
+        else           max_cpt = stg_inst <= 6 ? 24 : (stg_inst <= 8 ? 20 : 16);
+        const int env_cpt = std::getenv("GENPHI_MAX_CPT") ? std::atoi(std::getenv("GENPHI_MAX_CPT")) : 0;   // tuning hook: smaller chunks
+        if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
-        a.chunk_cols = (cpt + 3) / 4 * 4 * nt;                          // whole quads of columns per thread
+        const long long n_items = static_cast<long long>(dg.n_groups_s) * n_chunks;
+        if (certs) {
+            // ---- certified groups: level_split_fast_kernel ----
+            LevelArgs f = a;
+            int f_nt = 1024, f_chunks = 1 << 30, f_stg = stg_inst;
+            const int force_nt = std::getenv("GENPHI_FAST_NT") ? std::atoi(std::getenv("GENPHI_FAST_NT")) : 0;          // test / tuning hook
+            for (int nt : {1024, 512}) {
+                if (force_nt && nt != force_nt) continue;
+                int stg = (per_row4 + nt - 1) / nt;
+                if (nt == 512) stg = stg <= 12 ? 12 : (stg <= 14 ? 14 : (stg <= 16 ? 16 : 18)); else stg = stg_inst;
+                const int pt = static_cast<int>((s.ld + nt - 1) / nt);
+                int mc = fast_max_cpt(nt, stg);
+                if (env_cpt >= 4) mc = std::min(mc, env_cpt * (1024 / nt) / 4 * 4);
+                const int nch = (pt + mc - 1) / mc;
+                if (nch < f_chunks) { f_chunks = nch; f_nt = nt; f_stg = stg; }
+            }
+            const int f_pt = static_cast<int>((s.ld + f_nt - 1) / f_nt);
+            const int f_cpt = ((f_pt + f_chunks - 1) / f_chunks + 3) / 4 * 4;
+            const long long f_items = static_cast<long long>(dg.n_groups) * f_chunks;
+            // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
+            // group list) -> glist_s / gcnt[3]: decided on the device, per launch
+            int *glist_f = p->d_glist, *glist_s = p->d_glist + (static_cast<size_t>(p->plan.max_cut) + 64) / 64 * 64;
+            hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
+                               static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
+            hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp_s,
+                               static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
+                               gcnt + 2);
+            HIP_TRY(hipGetLastError());
+            f.glist = glist_f; f.gcnt = gcnt;
+            f.chunk_magic = chunk_magic_for(f_chunks);
+            const size_t f_lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(f_stg) * f_nt * 16);
+            f.slot_off = static_cast<int>(f_lds_stage / sizeof(float));
+            f.chunk_cols = f_cpt * f_nt;
+            f.n_chunks = f_chunks;
+            f.n_groups = dg.n_groups;
+            const int f_grid = static_cast<int>(std::min<long long>(p->n_cus, (f_items + 7) / 8 * 8));
+            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue)
+                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue));
+            a.zero_row = 0;                                                   // the fast launch wrote the "none" row
+            a.glist = glist_s; a.gcnt = gcnt + 2;
+        }
+        // ---- the other groups (all of them without certificates): level_split_kernel ----
+        a.slot_off = static_cast<int>(lds_stage_s / sizeof(float));
+        a.chunk_cols = (cpt + 3) / 4 * 4 * nt_s;                        // whole quads of columns per thread
         a.n_chunks = n_chunks;
-        a.n_groups = n_groups;
-        const long long n_items = static_cast<long long>(n_groups) * n_chunks;
+        a.chunk_magic = chunk_magic_for(n_chunks);
+        a.n_groups = dg.n_groups_s;
         const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
-        int *queue = p->d_queues + 8 * step;                                  // zeroed at the start of the sweep
-        HIP_TRY(s.pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, p->stream, a, desc, grp, queue)
-                          : launch_split<false>(cpt, stg_inst, grid, lds, p->stream, a, desc, grp, queue));
+        HIP_TRY(s.pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, p->stream, a, dg.desc, dg.grp_s, queue + 8)
+                          : launch_split<false>(cpt, stg_inst, grid, lds, p->stream, a, dg.desc, dg.grp_s, queue + 8));
     } else {
-        int wmax = 0;
-        for (const Segment &sg : s.segs) wmax = std::max(wmax, sg.win_len);
-        a.lds_row = (wmax + 4 + 3) / 4 * 4;
-        const size_t lds = 2 * static_cast<size_t>(a.lds_row) * sizeof(float);
-        HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_half_kernel), lds));
-        hipLaunchKernelGGL(level_half_kernel, dim3(n_rows), dim3(1024), lds, p->stream, a);
+        return fail(GENPHI_ERR_ARG, "internal: WIDE steps go through launch_wide_level");
     }
     HIP_TRY(hipGetLastError());
+    return GENPHI_OK;
+}
+
+// A WIDE level step (see rows_compact_kernel): out = the level matrix of the cut in its
+// [dragged..., new...] storage order, all rows.
+static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *out, int kernel)
+{
+    const LevelStep &s = p->plan.steps[step];
+    const DeviceStep &d = p->dsteps[step];
+    const LevelCtx cx = main_ctx(p, step);
+    const int n = static_cast<int>(s.n), nd = static_cast<int>(s.n_dragged), n_new = n - nd;
+    const int none = static_cast<int>(s.n_prev);
+    const unsigned thr = cert_threshold();
+    int *cert_out = cx.cert_out;
+    if (kernel == 1 || cx.identity) {
+        // the per-entry kernel and the 1/2 I kernel take any cut width: all rows in one launch
+        LevelCtx c2 = cx;
+        const int rc = launch_level(p, c2, psi, out, d.work, nullptr, n, kernel, d.groups);
+        if (rc) return rc;
+        if (kernel == 1) HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
+        return GENPHI_OK;
+    }
+    // 1. columns [0, nd) of every row: dragged rows are compacted copies, new rows compacted half sums
+    const bool nn_naive = s.nn_naive || s.nn.empty();
+    const int rows_1 = nn_naive ? nd : n;                 // (naive fallback: the new rows come whole from the per-entry kernel)
+    if (nd > 0 && rows_1 > 0) {
+        dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));
+        hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
+                           d.rowdesc, d.srcA, nd, out, static_cast<long long>(s.ld), cert_out, thr);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_new > 0) {
+        if (nn_naive) {
+            LevelArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.n_prev = none; a.n = n;
+            a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.rows = d.newrows; a.n_rows = n_new;
+            a.cert_out = cert_out; a.cert_thresh = thr;
+            dim3 grid(static_cast<unsigned>(n_new), static_cast<unsigned>((s.ld + 255) / 256));
+            hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
+            HIP_TRY(hipGetLastError());
+        } else {
+            // 2. Psi_P = Psi[parents][parents], with its zero padding and "none" row, and its rows' certificates
+            const LevelStep &nn = s.nn[0];
+            const DeviceStep &dn = p->nn_dsteps[d.nn];
+            const int n_par = static_cast<int>(nn.n_prev);
+            HIP_TRY(hipMemsetAsync(p->d_cert_p, 0, (static_cast<size_t>(n_par) + 1) * sizeof(int), p->stream));
+            if (n_par > 0) {
+                dim3 grid(static_cast<unsigned>(n_par), static_cast<unsigned>((n_par + 2047) / 2048));
+                hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
+                                   d.pardesc, d.parents, n_par, p->psi_p, static_cast<long long>(nn.ld_prev), p->d_cert_p, thr);
+            }
+            hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n_par + 1)), dim3(256), 0, p->stream, p->psi_p,
+                               static_cast<long long>(nn.ld_prev), n_par);
+            HIP_TRY(hipGetLastError());
+            // 3. the new x new block: a FULL / SPLIT level step on Psi_P into its own buffer
+            LevelCtx cn;
+            cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
+            cn.cert_prev = p->d_cert_p;
+            cn.cert_out = cert_out + nd;                                  // row r of the block is row nd + r of the cut
+            cn.identity = false; cn.dbg = false;
+            // (as an intermediate level of its own: the kernels also write the block's padding and "none" row)
+            const int rc = launch_level(p, cn, p->psi_p, p->nn_out, dn.work, nullptr, n_new, 0, dn.groups);
+            if (rc) return rc;
+            dim3 gc(static_cast<unsigned>(n_new), static_cast<unsigned>((n_new + 1023) / 1024));
+            hipLaunchKernelGGL(copy_block_kernel, gc, dim3(256), 0, p->stream, p->nn_out, static_cast<long long>(nn.ld), n_new, n_new,
+                               out, static_cast<long long>(s.ld), nd, nd);
+            HIP_TRY(hipGetLastError());
+        }
+        // 4. dragged x new = (new x dragged)^T
+        if (nd > 0) {
+            dim3 gt(static_cast<unsigned>((nd + 63) / 64), static_cast<unsigned>((n_new + 63) / 64));
+            hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(nd) * s.ld,
+                               static_cast<long long>(s.ld), n_new, nd, out, static_cast<long long>(s.ld), nd, cert_out, thr);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    // 5. padding columns and the "none" row
+    hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, p->stream, out, static_cast<long long>(s.ld), n);
+    HIP_TRY(hipGetLastError());
+    return GENPHI_OK;
+}
+
+static int ensure_doubles(double **ptr, size_t *have, size_t need)
+{
+    if (*have >= need && *ptr) return GENPHI_OK;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(double)));
+    *have = need;
+    return GENPHI_OK;
+}
+
+// The whole sweep with Float64 level matrices (see level_naive64_kernel): rows [r0, r1) of the
+// proband matrix end up in p->result64 (row pitch = pitch of the last cut).
+static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1)
+{
+    const Plan &pl = p->plan;
+    const int L = pl.n_levels, n_steps = L - 1;
+    const int64_t N = pl.n_pro, ldN = pl.ld[L - 1], n_rows = r1 - r0;
+    int rc = ensure_doubles(&p->result64, &p->result64_doubles, static_cast<size_t>(n_rows * ldN));
+    if (rc) return rc;
+    size_t need[2] = {0, 0};
+    for (int c = 0; c + 1 < L; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]));
+    for (int b = 0; b < 2; ++b)
+        if (need[b]) { rc = ensure_doubles(&p->buf64[b], &p->buf64_doubles[b], need[b]); if (rc) return rc; }
+    // storage member of each resident row (the last cut may be stored in [dragged, new] order)
+    std::vector<int> srow(n_rows), orow(n_rows);
+    for (int64_t k = 0; k < n_rows; ++k) { srow[k] = pl.final_perm.empty() ? static_cast<int>(r0 + k) : pl.final_perm[r0 + k]; orow[k] = static_cast<int>(k); }
+    if (static_cast<size_t>(2 * n_rows) > p->perm_rows_cap) {
+        if (p->d_perm_rows) { HIP_TRY(hipFree(p->d_perm_rows)); p->d_perm_rows = nullptr; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_perm_rows), 2 * n_rows * sizeof(int)));
+        p->perm_rows_cap = static_cast<size_t>(2 * n_rows);
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_perm_rows, srow.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_perm_rows + n_rows, orow.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));           // host vectors go out of scope
+    if (n_steps == 0) {
+        // all probands parentless: 1/2 I (src/compute.jl:271-274, loop skipped); members = probands in order
+        HIP_TRY(hipMemsetAsync(p->result64, 0, static_cast<size_t>(n_rows * ldN) * sizeof(double), p->stream));
+        std::vector<double> half(1, 0.5);
+        for (int64_t k = 0; k < n_rows; ++k)
+            HIP_TRY(hipMemcpyAsync(p->result64 + k * ldN + (r0 + k), half.data(), sizeof(double), hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return GENPHI_OK;
+    }
+    const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
+    HIP_TRY(hipMemsetAsync(p->buf64[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(double), p->stream));
+    hipLaunchKernelGGL(half_identity64_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0, p->stream, p->buf64[0],
+                       static_cast<long long>(ld0), static_cast<int>(n0), static_cast<const int *>(nullptr), static_cast<int>(n0),
+                       static_cast<const int *>(nullptr));
+    HIP_TRY(hipGetLastError());
+    for (int s = 0; s < n_steps; ++s) {
+        const LevelStep &st = pl.steps[s];
+        const DeviceStep &d = p->dsteps[s];
+        const double *psi = p->buf64[s & 1];
+        const bool last = s == n_steps - 1;
+        double *out = last ? p->result64 : p->buf64[(s + 1) & 1];
+        const int rows_n = last ? static_cast<int>(n_rows) : static_cast<int>(st.n);
+        dim3 grid(static_cast<unsigned>(rows_n), static_cast<unsigned>((st.ld + 255) / 256));
+        hipLaunchKernelGGL(level_naive64_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(st.ld_prev),
+                           static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), static_cast<int>(st.n), d.srcA, d.srcB, d.ord,
+                           last ? p->d_perm_rows : static_cast<const int *>(nullptr),
+                           last ? p->d_perm_rows + n_rows : static_cast<const int *>(nullptr),
+                           (last && !pl.final_perm.empty()) ? p->d_final_perm : static_cast<const int *>(nullptr),
+                           static_cast<int>(st.n));
+        HIP_TRY(hipGetLastError());
+        if (!last)           // the all-zero "none" row of this level
+            HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(double), p->stream));
+    }
+    (void)N;
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return GENPHI_OK;
 }
 
@@ -1321,6 +2118,11 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
 
     int rc = upload_plan(p, device);
     if (rc) return rc;
+    p->res_f64 = opts && (opts->reserved & GENPHI_FLAG_STORAGE_F64);
+    if (p->res_f64) {
+        p->res_ld = pl.ld[L - 1];
+        return compute_f64(p, r0, r1);
+    }
     const int n_steps = L - 1;
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
@@ -1333,22 +2135,20 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     rc = ensure_floats(p, &p->result, &p->result_floats, static_cast<size_t>(n_rows * ldN));
     if (rc) return rc;
     p->res_ld = ldN;
+    // last step WIDE: the whole level (every row, [dragged, new] storage order) goes to final_tmp,
+    // then rows [r0, r1) are delivered in proband order by colperm_kernel
     const bool need_perm = !pl.final_perm.empty();
     if (need_perm) {
-        rc = ensure_floats(p, &p->final_tmp, &p->final_tmp_floats, static_cast<size_t>(n_rows * ldN));
+        rc = ensure_floats(p, &p->final_tmp, &p->final_tmp_floats, static_cast<size_t>((N + 1) * ldN) + kTailPadFloats);
         if (rc) return rc;
     }
     // shard row lists for the last step: storage row of proband r, output row r - r0
     if (n_rows > p->shard_cap) {
         drop_graph(p);
-        if (p->d_shard_rows) {
-            HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows));
-            HIP_TRY(hipFree(p->d_shard_desc)); HIP_TRY(hipFree(p->d_shard_grp));
-        }
+        if (p->d_shard_rows) { HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows)); }
+        p->d_shard_rows = p->d_shard_out_rows = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_rows), n_rows * sizeof(int)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_desc), n_rows * sizeof(int4)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_grp), (n_rows + 1) * sizeof(int2)));
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
@@ -1363,12 +2163,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         }
         if (n_steps > 0) {
             const LevelStep &s = pl.steps[n_steps - 1];
-            if (s.mode == genphi::kModeHalf) {
-                std::stable_sort(key.begin(), key.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
-                    if (s.srcA[a.first] != s.srcA[b.first]) return s.srcA[a.first] < s.srcA[b.first];
-                    return s.srcB[a.first] < s.srcB[b.first];
-                });
-            } else {
+            if (s.mode != genphi::kModeWide) {          // (a WIDE last step computes every row, in storage order)
                 std::vector<int32_t> ord(n_rows);
                 std::vector<int> out_of(s.n, -1);
                 for (int64_t k = 0; k < n_rows; ++k) { ord[k] = key[k].first; out_of[key[k].first] = key[k].second; }
@@ -1379,13 +2174,27 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         for (int64_t k = 0; k < n_rows; ++k) { rows[k] = key[k].first; orows[k] = key[k].second; }
         HIP_TRY(hipMemcpyAsync(p->d_shard_rows, rows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(p->d_shard_out_rows, orows.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
-        std::vector<int4> desc;
-        std::vector<int2> grp;
+        p->shard_groups = DeviceGroups();
+        std::vector<char> gimg;
         if (n_steps > 0 && pl.steps[n_steps - 1].mode == genphi::kModeSplit) {
-            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), desc, grp);
-            p->shard_groups = static_cast<int>(grp.size()) - 1;
-            HIP_TRY(hipMemcpyAsync(p->d_shard_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(p->d_shard_grp, grp.data(), grp.size() * sizeof(int2), hipMemcpyHostToDevice, p->stream));
+            GroupLists gl;
+            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl);
+            const size_t gb = groups_bytes(gl);
+            if (gb > p->shard_blob_bytes) {
+                if (p->d_shard_blob) { HIP_TRY(hipFree(p->d_shard_blob)); p->d_shard_blob = nullptr; p->shard_blob_bytes = 0; }
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_blob), gb));
+                p->shard_blob_bytes = gb;
+            }
+            gimg.assign(gb, 0);
+            size_t goff = 0;
+            auto gput = [&](const void *src, size_t bytes) -> char * {
+                char *d = p->d_shard_blob + goff;
+                if (bytes) std::memcpy(gimg.data() + goff, src, bytes);
+                goff += al256(bytes);
+                return d;
+            };
+            put_groups(gl, p->shard_groups, gput);
+            HIP_TRY(hipMemcpyAsync(p->d_shard_blob, gimg.data(), gb, hipMemcpyHostToDevice, p->stream));
         }
         HIP_TRY(hipStreamSynchronize(p->stream));      // host vectors go out of scope
         p->shard_r0 = r0; p->shard_r1 = r1;
@@ -1396,12 +2205,12 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         const bool sharded = n_rows < pl.n_pro && n_steps >= 2 && std::getenv("GENPHI_NO_SHARD_PRUNE") == nullptr;
         if (sharded) {
             std::vector<std::vector<int>> host_rows(n_steps);
-            std::vector<std::vector<int4>> host_desc(n_steps);
-            std::vector<std::vector<int2>> host_grp(n_steps);
+            std::vector<GroupLists> host_gl(n_steps);
             std::vector<char> need(pl.steps[n_steps - 1].n_prev + 1, 0);            // members of cut n_steps-1
             {
                 const LevelStep &sl = pl.steps[n_steps - 1];
-                for (int64_t k = 0; k < n_rows; ++k) {
+                if (sl.mode == genphi::kModeWide) std::fill(need.begin(), need.end(), 1);
+                else for (int64_t k = 0; k < n_rows; ++k) {
                     const int i = rows[k];
                     if (sl.srcA[i] < sl.n_prev) need[sl.srcA[i]] = 1;
                     if (sl.srcB[i] < sl.n_prev) need[sl.srcB[i]] = 1;
@@ -1417,15 +2226,22 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     int fs = -1, fr = -1;
                     if (std::sscanf(e, "%d:%d", &fs, &fr) == 2 && fs == st && fr >= 0 && fr < static_cast<int>(need.size())) need[fr] = 1;
                 }
+                if (sv.mode == genphi::kModeWide) {                                  // computes every row, reads every row
+                    std::fill(need_prev.begin(), need_prev.end(), 1);
+                    need.swap(need_prev);
+                    continue;
+                }
                 for (int32_t i : sv.work)                                           // keep the planner's reuse order
                     if (need[i]) {
                         rw.push_back(i);
                         if (sv.srcA[i] < sv.n_prev) need_prev[sv.srcA[i]] = 1;
                         if (sv.srcB[i] < sv.n_prev) need_prev[sv.srcB[i]] = 1;
                     }
-                if (sv.mode == genphi::kModeSplit)
-                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_desc[st], host_grp[st]);
-                total += al(rw.size() * sizeof(int)) + al(host_desc[st].size() * sizeof(int4)) + al(host_grp[st].size() * sizeof(int2));
+                if (sv.mode == genphi::kModeSplit) {
+                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_gl[st]);
+                    total += groups_bytes(host_gl[st]);
+                }
+                total += al(rw.size() * sizeof(int));
                 need.swap(need_prev);
             }
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->sh_blob), total));
@@ -1441,11 +2257,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 genphi_plan::ShardStep &sh = p->sh_steps[st];
                 sh.n_rows = static_cast<int>(host_rows[st].size());
                 sh.rows = reinterpret_cast<int *>(put(host_rows[st].data(), host_rows[st].size() * sizeof(int)));
-                if (!host_grp[st].empty()) {
-                    sh.n_groups = static_cast<int>(host_grp[st].size()) - 1;
-                    sh.desc = reinterpret_cast<int4 *>(put(host_desc[st].data(), host_desc[st].size() * sizeof(int4)));
-                    sh.grp = reinterpret_cast<int2 *>(put(host_grp[st].data(), host_grp[st].size() * sizeof(int2)));
-                }
+                if (!host_gl[st].grp.empty()) put_groups(host_gl[st], sh.groups, put);
             }
             HIP_TRY(hipMemcpyAsync(p->sh_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
             HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1459,7 +2271,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     std::vector<int> ev_after(std::max(n_steps, 1));                             // event recorded after step k (timing)
     for (int k = 0; k < static_cast<int>(ev_after.size()); ++k) ev_after[k] = k + 1;
     auto enqueue = [&]() -> int {
-        HIP_TRY(hipMemsetAsync(p->d_queues, 0, (pl.steps.size() + 1) * 8 * sizeof(int), p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_queues, 0, p->n_slots * 16 * sizeof(int), p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_gcnt, 0, p->n_slots * 4 * sizeof(int), p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_cert, 0, std::max<size_t>(p->cert_words, 1) * sizeof(int), p->stream));
         if (n_steps == 0) {
             // all probands parentless: result = 1/2 I (src/compute.jl:271-274, loop skipped)
             HIP_TRY(hipMemsetAsync(p->result, 0, static_cast<size_t>(n_rows * ldN) * sizeof(float), p->stream));
@@ -1492,7 +2306,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));
                         hipLaunchKernelGGL(levels_small_kernel, dim3(1), dim3(1024), lds, p->stream, p->d_small + s, e - s,
                                            psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[e & 1],
-                                           static_cast<long long>(pl.ld[e]));
+                                           static_cast<long long>(pl.ld[e]), p->d_cert + p->cert_off[e], cert_threshold());
                         HIP_TRY(hipGetLastError());
                         // per-level timing: ONE event for the run, booked on its first step (an event
                         // record costs more than a fused level)
@@ -1506,20 +2320,24 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 }
                 if (!last) {
                     float *out = p->buf[(s + 1) & 1];
-                    if (p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step)
-                        rc = launch_level(p, s, psi, out, p->sh_steps[s].rows, nullptr, p->sh_steps[s].n_rows, kernel,
-                                          p->sh_steps[s].desc, p->sh_steps[s].grp, p->sh_steps[s].n_groups);
+                    if (st.mode == genphi::kModeWide)
+                        rc = launch_wide_level(p, s, psi, out, kernel);
+                    else if (p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step)
+                        rc = launch_level(p, main_ctx(p, s), psi, out, p->sh_steps[s].rows, nullptr, p->sh_steps[s].n_rows, kernel,
+                                          p->sh_steps[s].groups);
                     else
-                        rc = launch_level(p, s, psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
-                                          p->dsteps[s].desc, p->dsteps[s].grp, p->dsteps[s].n_groups);
+                        rc = launch_level(p, main_ctx(p, s), psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
+                                          p->dsteps[s].groups);
                     if (rc) return rc;
-                    // the all-zero "none" row of this level (FULL / SPLIT kernels write it themselves)
-                    if (kernel == 1 || st.mode == genphi::kModeHalf)
+                    // the all-zero "none" row of this level (FULL / SPLIT / WIDE launches write it themselves)
+                    if (kernel == 1 && st.mode != genphi::kModeWide)
                         HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
                 } else {
-                    float *out = need_perm ? p->final_tmp : p->result;
-                    rc = launch_level(p, s, psi, out, p->d_shard_rows, p->d_shard_out_rows, static_cast<int>(n_rows), kernel,
-                                      p->d_shard_desc, p->d_shard_grp, p->shard_groups);
+                    if (need_perm)
+                        rc = launch_wide_level(p, s, psi, p->final_tmp, kernel);
+                    else
+                        rc = launch_level(p, main_ctx(p, s), psi, p->result, p->d_shard_rows, p->d_shard_out_rows,
+                                          static_cast<int>(n_rows), kernel, p->shard_groups);
                     if (rc) return rc;
                     if (timing) HIP_TRY(hipEventRecord(p->events[n_steps + 1], p->stream));
                     if (need_perm) {
@@ -1533,7 +2351,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         const dim3 grid(static_cast<unsigned>(n_rows * n_chunks));
 #define GENPHI_CP(C) if (cpt <= C) { HIP_TRY(set_max_lds(reinterpret_cast<const void *>(colperm_kernel<C>), lds)); \
                         hipLaunchKernelGGL(colperm_kernel<C>, grid, dim3(1024), lds, p->stream, p->final_tmp, p->result, ldN, \
-                                           static_cast<int>(N), p->d_final_perm, n_chunks, seg_floats, n_segs); } else
+                                           static_cast<int>(N), p->d_final_perm, n_chunks, seg_floats, n_segs, static_cast<int>(r0)); } else
                         GENPHI_CP(8) GENPHI_CP(16) GENPHI_CP(24) GENPHI_CP(32) GENPHI_CP(40)
                         return fail(GENPHI_ERR_ARG, "internal: colperm geometry");
 #undef GENPHI_CP
@@ -1553,7 +2371,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     static const bool graphs_off = std::getenv("GENPHI_NO_GRAPH") != nullptr;
     const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0, p->alloc_gen};
     const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
-    const bool use_graph = !timing && !graphs_off && !(opts && (opts->reserved & 1)) && same_as_eager && n_steps >= 8;
+    const bool use_graph = !timing && !graphs_off && !(opts && (opts->reserved & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8;
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
     if (use_graph) {
         if (!p->graph_exec || std::memcmp(key, p->graph_key, sizeof(key)) != 0) {
@@ -1602,10 +2420,25 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
 int genphi_result_device(const genphi_plan *p, const float **d_ptr, int64_t *ld, int64_t *row_begin, int64_t *n_rows)
 {
     if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (p->res_f64) return fail(GENPHI_ERR_ARG, "the resident result is Float64 (GENPHI_FLAG_STORAGE_F64): use genphi_result_to_host_f64 / genphi_result_entries");
     if (d_ptr) *d_ptr = p->result;
     if (ld) *ld = p->res_ld;
     if (row_begin) *row_begin = p->res_row_begin;
     if (n_rows) *n_rows = p->res_n_rows;
+    return GENPHI_OK;
+}
+
+int genphi_result_to_host_f64(genphi_plan *p, double *out)
+{
+    if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    if (p->res_n_rows == 0 || p->plan.n_pro == 0) return GENPHI_OK;
+    if (!out) return fail(GENPHI_ERR_ARG, "out is NULL");
+    if (!p->res_f64 || !p->on_device || !p->result64)
+        return fail(GENPHI_ERR_ARG, "no resident Float64 result: call genphi_compute_device with GENPHI_FLAG_STORAGE_F64 first");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t N = static_cast<size_t>(p->plan.n_pro);
+    HIP_TRY(hipMemcpy2D(out, N * sizeof(double), p->result64, static_cast<size_t>(p->res_ld) * sizeof(double), N * sizeof(double),
+                        static_cast<size_t>(p->res_n_rows), hipMemcpyDeviceToHost));
     return GENPHI_OK;
 }
 
@@ -1614,6 +2447,15 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
     if (p->res_n_rows == 0 || p->plan.n_pro == 0) return GENPHI_OK;
     if (!out) return fail(GENPHI_ERR_ARG, "out is NULL");
+    if (p->res_f64) {
+        // Float64 sweep: deliver RN32 of the Float64 values (ONE rounding, like gen.f, src/compute.jl:500-511)
+        const size_t n = static_cast<size_t>(p->res_n_rows) * static_cast<size_t>(p->plan.n_pro);
+        std::vector<double> tmp(n);
+        const int rc = genphi_result_to_host_f64(p, tmp.data());
+        if (rc) return rc;
+        for (size_t k = 0; k < n; ++k) out[k] = static_cast<float>(tmp[k]);
+        return GENPHI_OK;
+    }
     if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
     HIP_TRY(hipSetDevice(p->device));
     const size_t N = static_cast<size_t>(p->plan.n_pro);
@@ -1703,6 +2545,7 @@ int genphi_result_sums(genphi_plan *p, double *sum_all, double *sum_diag, int64_
     if (sum_diag) *sum_diag = 0.0;
     if (n_rows_out) *n_rows_out = p->res_n_rows;
     if (p->res_n_rows == 0 || p->plan.n_pro == 0) return GENPHI_OK;
+    if (p->res_f64) return fail(GENPHI_ERR_ARG, "genphi_result_sums works on the Float32 result (phiMean's input type, src/compute.jl:454)");
     if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
     HIP_TRY(hipSetDevice(p->device));
     const int64_t nr = p->res_n_rows;
@@ -1729,7 +2572,8 @@ int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const 
     if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
     if (n < 0 || (n > 0 && (!rows || !cols || !out))) return fail(GENPHI_ERR_ARG, "genphi_result_entries: bad argument");
     if (n == 0) return GENPHI_OK;
-    if (!p->on_device || !p->result) return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
+    if (!p->on_device || !(p->res_f64 ? static_cast<const void *>(p->result64) : static_cast<const void *>(p->result)))
+        return fail(GENPHI_ERR_DEVICE, "no resident result: call genphi_compute_device first");
     const int64_t N = p->plan.n_pro, r0 = p->res_row_begin, nr = p->res_n_rows;
     std::vector<long long> off(static_cast<size_t>(n));
     for (int64_t k = 0; k < n; ++k) {
@@ -1746,8 +2590,12 @@ int genphi_result_entries(genphi_plan *p, int64_t n, const int64_t *rows, const 
     double *d_val = reinterpret_cast<double *>(p->scratch + off_bytes);
     hipError_t e = hipMemcpyAsync(d_off, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(gather_entries_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, p->stream,
-                           p->result, d_off, n, d_val);
+        if (p->res_f64)
+            hipLaunchKernelGGL(gather_entries64_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, p->stream,
+                               p->result64, d_off, n, d_val);
+        else
+            hipLaunchKernelGGL(gather_entries_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, p->stream,
+                               p->result, d_off, n, d_val);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_val, n * sizeof(double), hipMemcpyDeviceToHost, p->stream);
@@ -1770,6 +2618,55 @@ int genphi_debug_wg_phases(unsigned long long *out /* [2][1024][16] */)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), sizeof(unsigned long long) * 2 * 1024 * 16) == hipSuccess ? GENPHI_OK : GENPHI_ERR_DEVICE;
 }
 #endif
+
+int genphi_phi_pairs(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pairs,
+                     const int64_t *id_i, const int64_t *id_j, double *out, int32_t device)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && (!id_i || !id_j || !out))) return fail(GENPHI_ERR_ARG, "genphi_phi_pairs: bad argument");
+    if (n_pairs == 0) return GENPHI_OK;
+    // probands = the individuals named (first occurrences); one Float64 sweep; one lookup per pair
+    std::vector<int64_t> ids;
+    ids.reserve(static_cast<size_t>(2 * n_pairs));
+    for (int64_t k = 0; k < n_pairs; ++k) { ids.push_back(id_i[k]); ids.push_back(id_j[k]); }
+    genphi_plan *pl = nullptr;
+    int rc = genphi_plan_create(n_ind, ind, father, mother, static_cast<int64_t>(ids.size()), ids.data(), &pl);
+    if (rc) return rc;
+    // position of every named individual in the plan's proband order (duplicates collapsed in first-occurrence order)
+    std::vector<int64_t> uniq;
+    std::vector<int64_t> rows(n_pairs), cols(n_pairs);
+    {
+        std::vector<std::pair<int64_t, int64_t>> seen;      // (id, position); the sets are small
+        auto pos_of = [&](int64_t id) -> int64_t {
+            for (const auto &e : seen) if (e.first == id) return e.second;
+            seen.emplace_back(id, static_cast<int64_t>(seen.size()));
+            return seen.back().second;
+        };
+        if (ids.size() > 4096) {                            // many pairs: a sorted index instead of the linear scan
+            std::vector<int64_t> first;
+            std::vector<std::pair<int64_t, int64_t>> order;
+            for (size_t k = 0; k < ids.size(); ++k) order.emplace_back(ids[k], static_cast<int64_t>(k));
+            std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            std::vector<int64_t> first_occ(ids.size());
+            for (size_t k = 0; k < order.size(); ++k)
+                first_occ[order[k].second] = (k > 0 && order[k - 1].first == order[k].first) ? first_occ[order[k - 1].second] : order[k].second;
+            std::vector<int64_t> rank(ids.size(), -1);
+            int64_t next = 0;
+            for (size_t k = 0; k < ids.size(); ++k) if (first_occ[k] == static_cast<int64_t>(k)) rank[k] = next++;
+            for (int64_t k = 0; k < n_pairs; ++k) { rows[k] = rank[first_occ[2 * k]]; cols[k] = rank[first_occ[2 * k + 1]]; }
+        } else {
+            for (int64_t k = 0; k < n_pairs; ++k) { rows[k] = pos_of(id_i[k]); cols[k] = pos_of(id_j[k]); }
+        }
+    }
+    genphi_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.device = device; o.reserved = GENPHI_FLAG_STORAGE_F64;
+    rc = genphi_compute_device(pl, &o, nullptr);
+    if (rc == GENPHI_OK) rc = genphi_result_entries(pl, n_pairs, rows.data(), cols.data(), out);
+    const std::string keep = g_last_error;
+    genphi_plan_destroy(pl);
+    if (rc) g_last_error = keep;
+    return rc;
+}
 
 int genphi_compute_f32(genphi_plan *p, float *out, const genphi_opts *opts, genphi_stats *stats)
 {

@@ -7,13 +7,18 @@
 // Design here (not a translation): one pass over the generations stamps every individual
 // with the first and last parent-step distance at which it is reached; a cut is then
 // "everyone whose [first,last] interval covers that distance" (SURVEY.md A.2).  The order
-// inside intermediate cuts is free (A.2), so it is chosen for HBM/LDS locality of the level
-// kernels; only the last cut has a contractual order (proband first-occurrence order).
+// inside intermediate cuts is free (A.2), so it is chosen for the level kernels; only the last
+// cut has a contractual order (proband first-occurrence order).
+// Everything is linear: cuts are emitted already ordered (dragged members by scanning the
+// previous cut, new members from per-distance buckets filled in rank order), orderings by small
+// integer keys are counting sorts, and the per-step index arrays are built by a few threads.
 #include "planner.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 #include "../../include/genphi.h"
@@ -22,66 +27,158 @@ namespace genphi {
 
 namespace {
 
-struct Member {
-    int32_t x;        // pedigree rank index
-    int32_t A, B;     // sources in previous cut (n_prev = none)
-    int32_t bucket;   // LDS window of B in the previous cut (HALF mode) else 0
-    int32_t group;    // 1 = x is an LDS-side (B) source of the NEXT step (HALF mode) else 0
-    bool is_new;
+// stable counting sort of `in` by key[in[k]] (keys in [0, n_keys)) into `out`
+void counting_sort(const std::vector<int32_t> &in, std::vector<int32_t> &out, const std::vector<int32_t> &key,
+                   int32_t n_keys, std::vector<int32_t> &cnt)
+{
+    cnt.assign(static_cast<size_t>(n_keys) + 1, 0);
+    for (int32_t r : in) cnt[key[r] + 1]++;
+    for (int32_t k = 0; k < n_keys; ++k) cnt[k + 1] += cnt[k];
+    out.resize(in.size());
+    for (int32_t r : in) out[cnt[key[r]]++] = r;
+}
+
+// ID -> rank index.  Pedigree IDs are usually small dense integers: a direct table then; anything
+// else (sparse, huge or negative labels -- IDs are Julia Int) goes through a hash map.
+class IdMap {
+public:
+    void init(int64_t n, const int64_t *ind)
+    {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int64_t i = 0; i < n; ++i) { lo = std::min(lo, ind[i]); hi = std::max(hi, ind[i]); }
+        if (n > 0 && lo >= 0 && hi < 8 * n + 1024) {
+            table_.assign(static_cast<size_t>(hi) + 1, -1);
+            direct_ = true;
+        } else {
+            map_.reserve(static_cast<size_t>(n) * 2);
+        }
+    }
+    // false when the ID is already present
+    bool insert(int64_t id, int32_t rank)
+    {
+        if (direct_) {
+            if (table_[id] >= 0) return false;
+            table_[id] = rank;
+            return true;
+        }
+        return map_.emplace(id, rank).second;
+    }
+    int32_t find(int64_t id) const      // -1 when absent
+    {
+        if (direct_) return (id < 0 || id >= static_cast<int64_t>(table_.size())) ? -1 : table_[id];
+        auto it = map_.find(id);
+        return it == map_.end() ? -1 : it->second;
+    }
+private:
+    bool direct_ = false;
+    std::vector<int32_t> table_;
+    std::unordered_map<int64_t, int32_t> map_;
 };
+
+int mode_for(int64_t n_prev, const PlanOptions &opt)
+{
+    const int64_t lds_row = (n_prev + 1 + 3) / 4 * 4;
+    if (2 * lds_row <= opt.lds_cap_floats && lds_row <= opt.full_max_floats) return kModeFull;
+    if (lds_row <= opt.lds_cap_floats && n_prev < 65535) return kModeSplit;
+    return kModeWide;
+}
+
+}  // namespace
+
+namespace {
+// buffers of reuse_order, kept between calls of one planning run (fresh vectors cost page faults)
+struct ReuseScratch {
+    std::vector<int32_t> tmp, byA, byB, cnt, a_begin, a_end, b_begin, b_end, stack, out;
+    std::vector<char> seen;
+};
+
+void reuse_order_impl(const LevelStep &st, std::vector<int32_t> &rows, ReuseScratch &w)
+{
+    const int64_t m = static_cast<int64_t>(rows.size());
+    if (m == 0) return;
+    const int32_t none = static_cast<int32_t>(st.n_prev);
+    const int32_t n_keys = none + 1;
+    // rows by (A, B) -- runs of equal A are the sibling groups, "no B" sorts last inside a group --
+    // and by (B, A): two stable counting sorts each
+    counting_sort(rows, w.tmp, st.srcB, n_keys, w.cnt);
+    counting_sort(w.tmp, w.byA, st.srcA, n_keys, w.cnt);
+    counting_sort(rows, w.tmp, st.srcA, n_keys, w.cnt);
+    counting_sort(w.tmp, w.byB, st.srcB, n_keys, w.cnt);
+    // start offsets of every A value / B value present (values are < n_prev + 1)
+    w.a_begin.assign(n_keys + 1, -1); w.a_end.assign(n_keys + 1, -1);
+    w.b_begin.assign(n_keys + 1, -1); w.b_end.assign(n_keys + 1, -1);
+    for (int64_t k = 0; k < m; ++k) {
+        const int32_t A = st.srcA[w.byA[k]], B = st.srcB[w.byB[k]];
+        if (w.a_begin[A] < 0) w.a_begin[A] = static_cast<int32_t>(k);
+        w.a_end[A] = static_cast<int32_t>(k + 1);
+        if (w.b_begin[B] < 0) w.b_begin[B] = static_cast<int32_t>(k);
+        w.b_end[B] = static_cast<int32_t>(k + 1);
+    }
+    w.seen.assign(n_keys + 1, 0);
+    w.stack.clear();
+    w.out.clear();
+    w.out.reserve(m);
+    for (int64_t k0 = 0; k0 < m; ++k0) {
+        const int32_t A0 = st.srcA[w.byA[k0]];
+        if (w.seen[A0]) continue;
+        w.seen[A0] = 1;
+        w.stack.push_back(A0);
+        while (!w.stack.empty()) {
+            const int32_t A = w.stack.back();
+            w.stack.pop_back();
+            for (int32_t k = w.a_begin[A]; k < w.a_end[A]; ++k) {
+                const int32_t r = w.byA[k];
+                w.out.push_back(r);
+                const int32_t B = st.srcB[r];
+                if (B == none) continue;
+                for (int32_t t = w.b_begin[B]; t < w.b_end[B]; ++t) {      // the other children of this B source
+                    const int32_t A2 = st.srcA[w.byB[t]];
+                    if (!w.seen[A2]) { w.seen[A2] = 1; w.stack.push_back(A2); }
+                }
+            }
+        }
+    }
+    rows.assign(w.out.begin(), w.out.end());
+}
+// pk words, the position-test flag and the row processing order of a FULL / SPLIT step whose
+// srcA / srcB / ord are set
+void finish_narrow_step(LevelStep &st, ReuseScratch &w)
+{
+    const int64_t n = st.n, n_prev = st.n_prev;
+    st.pk.resize(n);
+    // column role: a dragged member is stored as A = B = itself, so every column
+    // carries weight 1/2 (x + x is exact) and the kernels need no per-column weight
+    for (int64_t k = 0; k < n; ++k) {
+        const uint32_t A = static_cast<uint32_t>(st.srcA[k]);
+        const uint32_t B = (st.ord[k] < 0) ? static_cast<uint32_t>(st.srcB[k]) : A;
+        st.pk[k] = A | (B << 16);
+    }
+    // position test usable instead of the rank word?  (new members with both parents must
+    // appear in rank order along the storage order: always so for [dragged, new by rank] cuts,
+    // a matter of luck for the proband order of the last cut)
+    bool mono = true;
+    int32_t last = -1;
+    for (int64_t k = 0; k < n && mono; ++k) {
+        if (st.ord[k] < 0 && st.srcB[k] != n_prev) {
+            const int32_t rk = st.ord[k] & INT32_MAX;
+            if (rk < last) mono = false;
+            last = rk;
+        }
+    }
+    st.pos_ord = mono;
+    // row processing order: sibling groups (same A source) adjacent, groups chained
+    // depth-first along shared B sources (see reuse_order)
+    st.work.resize(n);
+    std::iota(st.work.begin(), st.work.end(), 0);
+    reuse_order_impl(st, st.work, w);
+}
 
 }  // namespace
 
 void reuse_order(const LevelStep &st, std::vector<int32_t> &rows)
 {
-    const int64_t m = static_cast<int64_t>(rows.size());
-    if (m == 0) return;
-    const int32_t none = static_cast<int32_t>(st.n_prev);
-    // rows by (A, B): runs of equal A are the sibling groups ("no B" sorts last inside a group)
-    std::vector<int32_t> byA(rows);
-    std::sort(byA.begin(), byA.end(), [&](int32_t a, int32_t b) {
-        if (st.srcA[a] != st.srcA[b]) return st.srcA[a] < st.srcA[b];
-        if (st.srcB[a] != st.srcB[b]) return st.srcB[a] < st.srcB[b];
-        return a < b;
-    });
-    std::vector<int32_t> byB(rows);
-    std::sort(byB.begin(), byB.end(), [&](int32_t a, int32_t b) {
-        if (st.srcB[a] != st.srcB[b]) return st.srcB[a] < st.srcB[b];
-        return st.srcA[a] < st.srcA[b];
-    });
-    // start offsets of every A value / B value present (values are < n_prev + 1)
-    std::vector<int32_t> a_begin(st.n_prev + 2, -1), a_end(st.n_prev + 2, -1), b_begin(st.n_prev + 2, -1), b_end(st.n_prev + 2, -1);
-    for (int64_t k = 0; k < m; ++k) {
-        const int32_t A = st.srcA[byA[k]], B = st.srcB[byB[k]];
-        if (a_begin[A] < 0) a_begin[A] = static_cast<int32_t>(k);
-        a_end[A] = static_cast<int32_t>(k + 1);
-        if (b_begin[B] < 0) b_begin[B] = static_cast<int32_t>(k);
-        b_end[B] = static_cast<int32_t>(k + 1);
-    }
-    std::vector<char> seen(st.n_prev + 2, 0);
-    std::vector<int32_t> stack, out;
-    out.reserve(m);
-    for (int64_t k0 = 0; k0 < m; ++k0) {
-        const int32_t A0 = st.srcA[byA[k0]];
-        if (seen[A0]) continue;
-        seen[A0] = 1;
-        stack.push_back(A0);
-        while (!stack.empty()) {
-            const int32_t A = stack.back();
-            stack.pop_back();
-            for (int32_t k = a_begin[A]; k < a_end[A]; ++k) {
-                const int32_t r = byA[k];
-                out.push_back(r);
-                const int32_t B = st.srcB[r];
-                if (B == none) continue;
-                for (int32_t t = b_begin[B]; t < b_end[B]; ++t) {      // the other children of this B source
-                    const int32_t A2 = st.srcA[byB[t]];
-                    if (!seen[A2]) { seen[A2] = 1; stack.push_back(A2); }
-                }
-            }
-        }
-    }
-    rows.swap(out);
+    ReuseScratch w;
+    reuse_order_impl(st, rows, w);
 }
 
 int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
@@ -95,30 +192,28 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     if (n_ind >= (int64_t(1) << 31) - 1) { err = "pedigree too large (>= 2^31 individuals)"; return GENPHI_ERR_ARG; }
 
     // ---- id -> rank index; parents must precede children (src/create.jl:234-254) ----------
-    std::unordered_map<int64_t, int32_t> rank_of;
-    rank_of.reserve(static_cast<size_t>(n_ind) * 2);
+    IdMap rank_of;
+    rank_of.init(n_ind, ind);
     std::vector<int32_t> fa(n_ind), mo(n_ind);
     for (int64_t i = 0; i < n_ind; ++i) {
         int32_t f = -1, m = -1;
         if (father[i] != 0) {
-            auto it = rank_of.find(father[i]);
-            if (it == rank_of.end()) {
+            f = rank_of.find(father[i]);
+            if (f < 0) {
                 err = "individual " + std::to_string(ind[i]) + ": father " + std::to_string(father[i]) +
                       " is unknown or listed after its child (pedigree must be in rank order)";
                 return GENPHI_ERR_ORDER;
             }
-            f = it->second;
         }
         if (mother[i] != 0) {
-            auto it = rank_of.find(mother[i]);
-            if (it == rank_of.end()) {
+            m = rank_of.find(mother[i]);
+            if (m < 0) {
                 err = "individual " + std::to_string(ind[i]) + ": mother " + std::to_string(mother[i]) +
                       " is unknown or listed after its child (pedigree must be in rank order)";
                 return GENPHI_ERR_ORDER;
             }
-            m = it->second;
         }
-        if (!rank_of.emplace(ind[i], static_cast<int32_t>(i)).second) {
+        if (!rank_of.insert(ind[i], static_cast<int32_t>(i))) {
             err = "duplicate individual ID " + std::to_string(ind[i]);
             return GENPHI_ERR_DUPLICATE_ID;
         }
@@ -130,12 +225,12 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     std::vector<int32_t> cur;
     cur.reserve(n_pro);
     for (int64_t k = 0; k < n_pro; ++k) {
-        auto it = rank_of.find(pro_ids[k]);
-        if (it == rank_of.end()) {
+        const int32_t r = rank_of.find(pro_ids[k]);
+        if (r < 0) {
             err = "KeyError: proband " + std::to_string(pro_ids[k]) + " not found";
             return GENPHI_ERR_UNKNOWN_ID;
         }
-        if (stamp[it->second] != 0) { stamp[it->second] = 0; cur.push_back(it->second); }
+        if (stamp[r] != 0) { stamp[r] = 0; cur.push_back(r); }
     }
     plan = Plan();
     plan.n_ind = n_ind;
@@ -143,13 +238,12 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     plan.final_members = cur;
 
     // ---- generations by parent steps; t = distance from the probands ---------------------
-    std::vector<int32_t> seen;              // everyone reached, in discovery order
     int32_t t = 0;
     std::vector<int32_t> nxt;
     while (!cur.empty()) {
         nxt.clear();
         for (int32_t x : cur) {
-            if (tfirst[x] < 0) { tfirst[x] = t; seen.push_back(x); }
+            if (tfirst[x] < 0) tfirst[x] = t;
             tlast[x] = t;
             const int32_t f = fa[x], m = mo[x];
             if (f >= 0 && stamp[f] != t + 1) { stamp[f] = t + 1; nxt.push_back(f); }
@@ -162,16 +256,28 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     plan.n_levels = L;
     if (L == 0) return GENPHI_OK;
 
-    // cut c (c = 0 top founders ... L-1 probands) = { x : tfirst <= L-1-c <= tlast }
-    std::vector<std::vector<int32_t>> cut(L);
+    // cut c (c = 0 top founders ... L-1 probands) = { x : tfirst <= d_c <= tlast }, d_c = L-1-c.
+    // x is NEW in cut c iff tlast[x] == d_c (it is not in cut c-1); bucket the individuals by
+    // tlast while scanning them in rank order: every bucket comes out rank-sorted.
+    std::vector<std::vector<int32_t>> new_of(L);
     {
         std::vector<int64_t> cnt(L, 0);
-        for (int32_t x : seen) for (int32_t d = tfirst[x]; d <= tlast[x]; ++d) cnt[L - 1 - d]++;
-        for (int32_t c = 0; c < L; ++c) cut[c].reserve(cnt[c]);
-        for (int32_t x : seen) for (int32_t d = tfirst[x]; d <= tlast[x]; ++d) cut[L - 1 - d].push_back(x);
+        for (int64_t x = 0; x < n_ind; ++x) if (tlast[x] >= 0) cnt[L - 1 - tlast[x]]++;
+        for (int32_t c = 0; c < L; ++c) new_of[c].reserve(cnt[c]);
+        for (int64_t x = 0; x < n_ind; ++x) if (tlast[x] >= 0) new_of[L - 1 - tlast[x]].push_back(static_cast<int32_t>(x));
     }
-    cut[L - 1] = plan.final_members;         // contractual order of the result
 
+    // ---- storage order of every cut: [dragged by previous position..., new by rank...];
+    //      the last cut keeps the proband order (contractual) unless its step is WIDE ----------
+    std::vector<std::vector<int32_t>> cut(L);
+    cut[0] = new_of[0];
+    for (int32_t c = 1; c < L; ++c) {
+        const int32_t d = L - 1 - c;
+        std::vector<int32_t> &cc = cut[c];
+        cc.reserve(cut[c - 1].size() + new_of[c].size());
+        for (int32_t x : cut[c - 1]) if (tfirst[x] <= d) cc.push_back(x);       // dragged: still needed below
+        cc.insert(cc.end(), new_of[c].begin(), new_of[c].end());
+    }
     plan.cut_sizes.resize(L);
     plan.ld.resize(L);
     for (int32_t c = 0; c < L; ++c) {
@@ -179,177 +285,117 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         plan.ld[c] = pitch_for(plan.cut_sizes[c]);
         plan.max_cut = std::max(plan.max_cut, plan.cut_sizes[c]);
     }
-    plan.both_counts.assign(L > 0 ? L - 1 : 0, 0);
+    const bool last_wide = L >= 2 && mode_for(plan.cut_sizes[L - 2], opt) == kModeWide;
+    if (!last_wide) {
+        cut[L - 1] = plan.final_members;
+    } else {
+        std::vector<int32_t> pos(n_ind, -1);
+        for (size_t k = 0; k < cut[L - 1].size(); ++k) pos[cut[L - 1][k]] = static_cast<int32_t>(k);
+        plan.final_perm.resize(plan.final_members.size());
+        for (size_t k = 0; k < plan.final_members.size(); ++k) plan.final_perm[k] = pos[plan.final_members[k]];
+    }
+    plan.both_counts.assign(L - 1, 0);
     plan.steps.resize(L - 1);
 
-    // x in cut c is "dragged" in step c-1 -> c iff it is also in cut c-1, i.e. tlast[x] > L-1-c
-    auto is_dragged = [&](int32_t x, int32_t c) { return tlast[x] > L - 1 - c; };
-    auto step_mode = [&](int32_t c_prev) {      // step c_prev -> c_prev+1
-        const int64_t lds_row = (plan.cut_sizes[c_prev] + 1 + 3) / 4 * 4;
-        if (2 * lds_row <= opt.lds_cap_floats && lds_row <= opt.full_max_floats) return int(kModeFull);
-        if (lds_row <= opt.lds_cap_floats && plan.cut_sizes[c_prev] < 65535) return int(kModeSplit);
-        return int(kModeHalf);
-    };
-    auto step_is_half = [&](int32_t c_prev) { return step_mode(c_prev) == kModeHalf; };
-
-    // ---- order the cuts top-down and emit the flat index arrays ----------------------------
-    std::vector<int32_t> pos_prev(n_ind, -1), pos_cur(n_ind, -1), mark(n_ind, -1);
-    std::vector<Member> mem;
-    int64_t s2_begin_prev = 0, win_len_prev = 0;   // LDS windows of the previous cut (HALF steps)
-    for (int32_t c = 0; c < L; ++c) {
-        const int64_t n = plan.cut_sizes[c];
-        const int64_t n_prev = c > 0 ? plan.cut_sizes[c - 1] : 0;
-        const bool in_half = c > 0 && step_is_half(c - 1);        // step producing this cut
-        const bool out_half = c + 1 < L && step_is_half(c);       // step consuming this cut
-        // who is an LDS-side (B) source of the next step?
-        if (out_half) {
-            for (int32_t y : cut[c + 1]) {
-                if (!is_dragged(y, c + 1) && fa[y] >= 0 && mo[y] >= 0) mark[mo[y]] = c;
+    // ---- positions chain through the cuts: one serial, linear pass snapshots, for every member
+    //      of cut c, the positions of its sources in cut c-1 (-1 = none) ----------------------------
+    std::vector<std::vector<int32_t>> posA(L), posB(L);
+    {
+        std::vector<int32_t> pos_even(n_ind, -1), pos_odd(n_ind, -1);
+        auto pos_of = [&](int32_t c) -> std::vector<int32_t> & { return (c & 1) ? pos_odd : pos_even; };
+        for (size_t k = 0; k < cut[0].size(); ++k) pos_of(0)[cut[0][k]] = static_cast<int32_t>(k);
+        for (int32_t c = 1; c < L; ++c) {
+            const std::vector<int32_t> &pp = pos_of(c - 1);
+            const int32_t d = L - 1 - c;
+            const size_t n = cut[c].size();
+            posA[c].resize(n); posB[c].resize(n);
+            for (size_t k = 0; k < n; ++k) {
+                const int32_t x = cut[c][k];
+                if (tlast[x] > d) { posA[c][k] = pp[x]; posB[c][k] = -1; }            // dragged: also in cut c-1
+                else { posA[c][k] = fa[x] >= 0 ? pp[fa[x]] : -1; posB[c][k] = mo[x] >= 0 ? pp[mo[x]] : -1; }
             }
+            std::vector<int32_t> &pc = pos_of(c);
+            for (size_t k = 0; k < n; ++k) pc[cut[c][k]] = static_cast<int32_t>(k);
         }
-        mem.resize(n);
+    }
+
+    // ---- the flat index arrays of every step: independent of each other, built by a few threads ----
+    auto build_step = [&](int32_t c, ReuseScratch &w) {
+        LevelStep &st = plan.steps[c - 1];
+        const int64_t n = plan.cut_sizes[c], n_prev = plan.cut_sizes[c - 1];
+        const int32_t d = L - 1 - c;
+        st.n_prev = n_prev; st.n = n;
+        st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
+        st.mode = mode_for(n_prev, opt);
+        st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
+        const int32_t none = static_cast<int32_t>(n_prev);
+        int64_t dragged = 0;
         for (int64_t k = 0; k < n; ++k) {
-            Member &m = mem[k];
             const int32_t x = cut[c][k];
-            m.x = x; m.bucket = 0; m.group = (out_half && mark[x] == c) ? 1 : 0;
-            if (c == 0) { m.A = m.B = 0; m.is_new = true; continue; }
-            if (is_dragged(x, c)) { m.is_new = false; m.A = pos_prev[x]; m.B = static_cast<int32_t>(n_prev); }
+            const int32_t a = posA[c][k], b = posB[c][k];
+            if (tlast[x] > d) { st.srcA[k] = a; st.srcB[k] = none; st.ord[k] = x; ++dragged; }
             else {
-                m.is_new = true;
-                const int32_t f = fa[x], mm = mo[x];
-                if (f >= 0 && mm >= 0) { m.A = pos_prev[f]; m.B = pos_prev[mm]; }
-                else if (f >= 0) { m.A = pos_prev[f]; m.B = static_cast<int32_t>(n_prev); }
-                else if (mm >= 0) { m.A = pos_prev[mm]; m.B = static_cast<int32_t>(n_prev); }
-                else { m.A = m.B = static_cast<int32_t>(n_prev); }
+                if (a >= 0 && b >= 0) { st.srcA[k] = a; st.srcB[k] = b; }
+                else if (a >= 0) { st.srcA[k] = a; st.srcB[k] = none; }
+                else if (b >= 0) { st.srcA[k] = b; st.srcB[k] = none; }
+                else { st.srcA[k] = st.srcB[k] = none; }
+                st.ord[k] = x | kNewFlag;
             }
-            if (in_half && m.B != n_prev) m.bucket = static_cast<int32_t>((m.B - s2_begin_prev) / win_len_prev);
         }
-        // storage order: intermediate cuts by (group, bucket, A, B); the last cut keeps the
-        // proband order unless its step is HALF (then a locality order + final_perm).
-        const bool reorder = (c < L - 1) || in_half;
-        std::vector<int32_t> order(n);
-        std::iota(order.begin(), order.end(), 0);
-        // FULL / SPLIT steps: [dragged by previous position..., new by rank...] so that the
-        // kernels need no per-column rank word; HALF steps keep their window-bucket order
-        const bool pos_ord = reorder && c > 0 && !in_half && !out_half;
-        if (pos_ord) {
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-                const Member &p = mem[a], &q = mem[b];
-                if (p.is_new != q.is_new) return !p.is_new;
-                if (!p.is_new) return p.A < q.A;
-                return p.x < q.x;
-            });
-        } else if (reorder && c > 0) {
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-                const Member &p = mem[a], &q = mem[b];
-                if (p.group != q.group) return p.group < q.group;
-                if (p.bucket != q.bucket) return p.bucket < q.bucket;
-                if (p.A != q.A) return p.A < q.A;
-                return p.B < q.B;
-            });
-        } else if (reorder) {
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return mem[a].group < mem[b].group; });
-        }
-        for (int64_t k = 0; k < n; ++k) pos_cur[mem[order[k]].x] = static_cast<int32_t>(k);
-        if (c == L - 1 && reorder) {
-            plan.final_perm.resize(n);
-            for (int64_t k = 0; k < n; ++k) plan.final_perm[k] = pos_cur[plan.final_members[k]];
-        }
+        st.n_dragged = dragged;
+        plan.both_counts[c - 1] = dragged;
+        if (st.mode != kModeWide) { finish_narrow_step(st, w); return; }
 
-        if (c > 0) {
-            LevelStep &st = plan.steps[c - 1];
-            st.n_prev = n_prev; st.n = n;
-            st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
-            st.mode = step_mode(c - 1);
-            st.pos_ord = pos_ord;
-            st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
-            int64_t dragged = 0;
-            for (int64_t k = 0; k < n; ++k) {
-                const Member &m = mem[order[k]];
-                st.srcA[k] = m.A; st.srcB[k] = m.B;
-                st.ord[k] = m.x | (m.is_new ? kNewFlag : 0);
-                dragged += m.is_new ? 0 : 1;
-            }
-            st.n_dragged = dragged;
-            if (st.mode != kModeHalf) {
-                st.pk.resize(n);
-                // column role: a dragged member is stored as A = B = itself, so every column
-                // carries weight 1/2 (x + x is exact) and the kernels need no per-column weight
-                for (int64_t k = 0; k < n; ++k) {
-                    const uint32_t A = static_cast<uint32_t>(st.srcA[k]);
-                    const uint32_t B = (st.ord[k] < 0) ? static_cast<uint32_t>(st.srcB[k]) : A;
-                    st.pk[k] = A | (B << 16);
-                }
-                // position test usable instead of the rank word?  (new members with both
-                // parents must appear in rank order along the storage order)
-                if (!st.pos_ord) {
-                    bool mono = true;
-                    int32_t last = -1;
-                    for (int64_t k = 0; k < n && mono; ++k) {
-                        if (st.ord[k] < 0 && st.srcB[k] != n_prev) {
-                            const int32_t rk = st.ord[k] & INT32_MAX;
-                            if (rk < last) mono = false;
-                            last = rk;
-                        }
-                    }
-                    st.pos_ord = mono;
-                }
-            }
-            plan.both_counts[c - 1] = dragged;
-            // row processing order: sibling groups (same A source) adjacent, groups chained
-            // depth-first along shared B sources (see reuse_order)
-            st.work.resize(n);
-            std::iota(st.work.begin(), st.work.end(), 0);
-            if (in_half) {
-                std::stable_sort(st.work.begin(), st.work.end(), [&](int32_t a, int32_t b) {
-                    if (st.srcA[a] != st.srcA[b]) return st.srcA[a] < st.srcA[b];
-                    return st.srcB[a] < st.srcB[b];
-                });
-            } else {
-                reuse_order(st, st.work);
-            }
-            if (in_half) {
-                // column segments: runs of equal (group, bucket); processed bucket-major so a
-                // window is staged once per row
-                st.b_rel.resize(n);
-                struct Run { int32_t b, e, bucket; };
-                std::vector<Run> runs;
-                for (int64_t k = 0; k < n;) {
-                    const Member &m0 = mem[order[k]];
-                    int64_t e = k + 1;
-                    while (e < n && mem[order[e]].group == m0.group && mem[order[e]].bucket == m0.bucket) ++e;
-                    runs.push_back({static_cast<int32_t>(k), static_cast<int32_t>(e), m0.bucket});
-                    k = e;
-                }
-                std::stable_sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.bucket < b.bucket; });
-                for (const Run &r : runs) {
-                    Segment sg;
-                    sg.col_begin = r.b; sg.col_end = r.e;
-                    sg.win_begin = static_cast<int32_t>(s2_begin_prev + int64_t(r.bucket) * win_len_prev);
-                    sg.win_len = static_cast<int32_t>(std::min<int64_t>(win_len_prev, n_prev - sg.win_begin));
-                    // the zero slot sits right after the window: include the matrix's own zero
-                    // column when the window reaches the end of the row
-                    for (int32_t k = r.b; k < r.e; ++k) {
-                        const int32_t B = st.srcB[k];
-                        st.b_rel[k] = (B == n_prev) ? sg.win_len : B - sg.win_begin;
-                    }
-                    st.segs.push_back(sg);
-                }
-            }
+        // WIDE: the cut is [dragged..., new...]; the new x new block becomes a step of its own
+        // over the compacted parent x parent matrix Psi[parents][parents]
+        st.work.resize(n);
+        std::iota(st.work.begin(), st.work.end(), 0);
+        const int64_t n_new = n - dragged;
+        std::vector<char> is_par(n_prev + 1, 0);
+        for (int64_t k = dragged; k < n; ++k) { is_par[st.srcA[k]] = 1; is_par[st.srcB[k]] = 1; }
+        is_par[none] = 0;
+        std::vector<int32_t> pidx(n_prev + 1, -1);
+        for (int64_t q = 0; q < n_prev; ++q)
+            if (is_par[q]) { pidx[q] = static_cast<int32_t>(st.parents.size()); st.parents.push_back(static_cast<int32_t>(q)); }
+        const int64_t n_par = static_cast<int64_t>(st.parents.size());
+        const int nn_mode = mode_for(n_par, opt);
+        if (nn_mode == kModeWide) { st.nn_naive = true; return; }
+        st.nn.resize(1);
+        LevelStep &nn = st.nn[0];
+        nn.n_prev = n_par; nn.n = n_new;
+        nn.ld_prev = pitch_for(n_par); nn.ld = pitch_for(n_new);
+        nn.mode = nn_mode;
+        nn.srcA.resize(n_new); nn.srcB.resize(n_new); nn.ord.resize(n_new);
+        const int32_t pnone = static_cast<int32_t>(n_par);
+        for (int64_t k = 0; k < n_new; ++k) {
+            const int32_t A = st.srcA[dragged + k], B = st.srcB[dragged + k];
+            nn.srcA[k] = A == none ? pnone : pidx[A];
+            nn.srcB[k] = B == none ? pnone : pidx[B];
+            nn.ord[k] = st.ord[dragged + k];
         }
-        // LDS windows over this cut for the next step
-        if (out_half) {
-            int64_t s2 = n;
-            for (int64_t k = 0; k < n; ++k) if (mem[order[k]].group == 1) { s2 = k; break; }
-            s2 = s2 / 4 * 4;
-            const int64_t n_s2 = std::max<int64_t>(n - s2, 1);
-            const int64_t wmax = std::max<int64_t>((opt.lds_cap_floats / 2 - 4) / 4 * 4, 4);
-            const int64_t n_win = (n_s2 + wmax - 1) / wmax;
-            int64_t w = (n_s2 + n_win - 1) / n_win;
-            w = (w + 3) / 4 * 4;
-            s2_begin_prev = s2; win_len_prev = w;
-        } else { s2_begin_prev = 0; win_len_prev = 1; }
-        pos_prev.swap(pos_cur);
+        nn.n_dragged = 0;
+        finish_narrow_step(nn, w);
+    };
+    // single-threaded by default: the steps are short and fresh threads cost more than they save on
+    // small hosts (measured: 1 thread 0.10 s, 8 threads 0.12 s for cfg4); GENPHI_PLAN_THREADS overrides
+    int n_thr = 1;
+    if (const char *e = std::getenv("GENPHI_PLAN_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(e)));
+    n_thr = std::min(n_thr, std::max(1, L - 1));
+    if (n_thr <= 1) {
+        ReuseScratch w;
+        for (int32_t c = 1; c < L; ++c) build_step(c, w);
+    } else {
+        std::vector<std::thread> th;
+        std::vector<char> oom(n_thr, 0);
+        for (int t2 = 0; t2 < n_thr; ++t2)
+            th.emplace_back([&, t2]() {
+                try {
+                    ReuseScratch w;
+                    for (int32_t c = L - 1 - t2; c >= 1; c -= n_thr) build_step(c, w);      // the big last step first
+                } catch (const std::bad_alloc &) { oom[t2] = 1; }
+            });
+        for (auto &x : th) x.join();
+        for (char e : oom) if (e) throw std::bad_alloc();
     }
 
     double bytes = 0.0;

@@ -16,6 +16,12 @@
 //
 // "none" is encoded as index n_prev: every level matrix carries one extra all-zero row
 // and zero columns up to its pitch, so kernels gather unconditionally.
+//
+// Storage order of a cut (free for intermediate cuts):
+//   [dragged members by their position in the previous cut ..., new members by rank ...]
+// so that (i) "row member has the larger rank" is a position test among new members, (ii) the
+// sources of the dragged columns increase monotonically (a level's dragged x dragged block is a
+// stream compaction of the previous matrix), (iii) the new x new block is contiguous.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -25,12 +31,14 @@ namespace genphi {
 
 constexpr int32_t kNewFlag = INT32_MIN;     // bit 31 of `ord`: member is new (weight 1/2)
 
-enum { kModeFull = 0, kModeSplit = 1, kModeHalf = 2 };
-
-struct Segment {            // HALF-mode column segment (see kernels): columns [col_begin,col_end)
-    int32_t col_begin, col_end;   // of cut s+1 take their B source from LDS window
-    int32_t win_begin, win_len;   // [win_begin, win_begin+win_len) of cut s
-};
+// Kernel family of a level step, by the width of the previous cut:
+//   FULL   both source rows of an output row fit in LDS
+//   SPLIT  one source row at a time fits (persistent pipelined kernels, certified fast path)
+//   WIDE   a source row does not fit in LDS (or indices need more than 16 bits): the level is
+//          assembled from streaming passes -- dragged x dragged and new x dragged blocks by row
+//          compaction, dragged x new by transposition, new x new by a FULL / SPLIT sub-step on
+//          the compacted parent x parent matrix (LevelStep::parents / nn)
+enum { kModeFull = 0, kModeSplit = 1, kModeWide = 2 };
 
 struct LevelStep {
     int64_t n_prev = 0, n = 0;        // |cut s|, |cut s+1|
@@ -41,13 +49,17 @@ struct LevelStep {
     std::vector<int32_t> ord;         // pedigree rank index (0-based) | kNewFlag
     std::vector<int32_t> work;        // row processing order (rows sharing srcA adjacent)
     std::vector<uint32_t> pk;         // srcA | srcB << 16 (FULL / SPLIT modes)
-    // kernel mode, by how much of the two source rows fits in LDS:
-    //   FULL  both rows whole; SPLIT one row at a time; HALF a window of the B side (fallback)
     int mode = 0;
-    bool pos_ord = false;             // cut s+1 is stored [dragged by A..., new by rank...]: kernels
-                                      // derive "new" and the rank comparison from positions
-    std::vector<Segment> segs;        // HALF only
-    std::vector<int32_t> b_rel;       // per column: B source relative to its segment's window; win_len = none
+    bool pos_ord = false;             // new members with both parents appear in rank order along the
+                                      // storage order: kernels use the position test instead of rank words
+    // WIDE only.  The cut is stored [dragged..., new...] (n_dragged, n - n_dragged).
+    std::vector<int32_t> parents;     // distinct parents of the new members: positions in cut s, ascending
+    // the new x new block as a level step of its own over Psi_P = Psi[parents][parents]:
+    // n_prev = |parents|, n = n_new, sources = indices into `parents` (|parents| = none); mode FULL
+    // or SPLIT (0 or 1 element; empty with nn_naive when |parents| is too wide even for SPLIT:
+    // the block then comes from the per-entry kernel on Psi itself)
+    std::vector<LevelStep> nn;
+    bool nn_naive = false;
 };
 
 struct Plan {
@@ -59,8 +71,8 @@ struct Plan {
     std::vector<int64_t> ld;                 // row pitch of each cut's matrix
     std::vector<LevelStep> steps;            // L-1 entries
     std::vector<int32_t> final_members;      // rank index of each proband, result order
-    // Final cut is kept in a locality order when its step runs in HALF mode; perm maps
-    // result (proband) position -> storage position.  Empty = storage order is proband order.
+    // The final cut is kept in [dragged, new] order when its step is WIDE; perm maps result
+    // (proband) position -> storage position.  Empty = storage order is proband order.
     std::vector<int32_t> final_perm;
     double algorithmic_bytes = 0.0;          // 4 * sum (n_k^2 + n_{k+1}^2)
     int64_t max_cut = 0;

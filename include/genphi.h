@@ -47,8 +47,13 @@ typedef struct genphi_opts {
     int64_t row_begin;     /* final-level row shard [row_begin,row_end) in proband order;   */
     int64_t row_end;       /*   row_end <= 0 means "all rows" (multi-GPU: one shard/rank)   */
     int32_t timing;        /* !=0: record per-level HIP-event timings into genphi_stats     */
-    int32_t reserved;      /* bit 0: never replay the sweep from a captured hipGraph         */
+    int32_t reserved;      /* flags, GENPHI_FLAG_* below (the field keeps its round-1 name)   */
 } genphi_opts;
+
+#define GENPHI_FLAG_NO_GRAPH     1   /* never replay the sweep from a captured hipGraph                         */
+#define GENPHI_FLAG_STORAGE_F64  2   /* Float64 level matrices: the values of the reference's Float64 pairwise
+                                        recursion (src/compute.jl:66-95) instead of gen.phi's Float32-per-level
+                                        matrices; for gen.f / pairwise queries (per-entry kernel, small sets)   */
 
 #define GENPHI_MAX_STAT_LEVELS 1024
 typedef struct genphi_stats {
@@ -82,10 +87,17 @@ int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels,
 /* Number of distinct probands N (rows/columns of the result, proband first-occurrence order). */
 int64_t genphi_plan_n_probands(const genphi_plan *plan);
 
-/* Kernel variant the planner chose for level step `step` (0-based, < n_levels-1):
- * 0 = FULL (both source rows in LDS), 1 = SPLIT (one row at a time), 2 = HALF (windowed
- * fallback); -1 on a bad argument.  Diagnostic only (tests assert every variant is covered). */
+/* Kernel family the planner chose for level step `step` (0-based, < n_levels-1):
+ * 0 = FULL (both source rows of an output row in LDS), 1 = SPLIT (one row at a time),
+ * 2 = WIDE (a source row does not fit in LDS: the level is assembled block by block from
+ * streaming passes); -1 on a bad argument.  Diagnostic only (tests assert every variant is covered). */
 int genphi_plan_step_mode(const genphi_plan *plan, int32_t step);
+
+/* More of the same: info[0] = mode, info[1] = members dragged from the previous cut, info[2] =
+ * distinct parents of the new members (WIDE steps, else 0), info[3] = how a WIDE step computes its
+ * new x new block: 0 / 1 = a FULL / SPLIT sub-step on the compacted parent matrix, 3 = per-entry
+ * kernel (parents too wide as well); -1 for the other modes.                                    */
+int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info);
 
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);
@@ -107,6 +119,21 @@ int genphi_result_device(const genphi_plan *plan, const float **d_ptr, int64_t *
  * (== column-major for the symmetric full matrix, so a Julia Matrix{Float32}(undef,N,N)
  * can be passed directly when all rows were computed).                                       */
 int genphi_result_to_host(genphi_plan *plan, float *out);
+
+/* Float64 counterpart for results computed with GENPHI_FLAG_STORAGE_F64: out is (n_rows x N) dense
+ * row-major Float64.  (genphi_result_to_host on such a result delivers RN32 of these values: one
+ * rounding, which is what gen.f returns, src/compute.jl:500-511.)                                  */
+int genphi_result_to_host_f64(genphi_plan *plan, double *out);
+
+/* phi(individual_i, individual_j) (src/compute.jl:66-95: the exact Float64 Karigl recursion,
+ * un-memoised and exponential on inbred pedigrees) for n_pairs pairs of IDs at once: one Float64
+ * level sweep over the individuals named, one lookup per pair.  out[k] = Phi(id_i[k], id_j[k])
+ * (id_i[k] == id_j[k] gives the self-kinship 1/2 + Phi(father, mother)/2).  Bit-identical to the
+ * recursion while every kinship is exactly representable in Float64 (pedigrees less than ~26
+ * generations deep), within 1e-15 relative beyond.  Pedigree arguments as for genphi_plan_create;
+ * unknown ID -> GENPHI_ERR_UNKNOWN_ID.                                                              */
+int genphi_phi_pairs(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                     int64_t n_pairs, const int64_t *id_i, const int64_t *id_j, double *out, int32_t device);
 
 /* On-device reduction for phiMean(::Matrix{Float32}) (src/compute.jl:454-459) without moving the
  * matrix to the host: Float64 sum of all resident entries and of their diagonal entries.
@@ -151,6 +178,12 @@ int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, c
                      const int64_t *sex, int64_t n_pro, const int64_t *pro, int64_t n_anc,
                      const int64_t *ancestors, int64_t *n_out, int64_t **ind_out, int64_t **father_out,
                      int64_t **mother_out, int64_t **sex_out);
+
+/* Releases everything the plan holds on its GPU (index arrays, level matrices, the resident
+ * result, streams, captured graphs) and keeps the host-side plan: the next genphi_compute_device
+ * uploads again, on the same or on another device (opts->device).  The reference has no
+ * counterpart (its matrices are garbage-collected Julia arrays, src/compute.jl:291,301).      */
+int genphi_plan_release_device(genphi_plan *plan);
 
 /* Frees host and device memory of the plan (NULL is allowed). */
 void genphi_plan_destroy(genphi_plan *plan);

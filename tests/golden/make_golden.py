@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import oracle as O  # noqa: E402
 
-ped = O.Pedigree.from_file(os.path.join(HERE, "genea140.csv"))
+ped = O.Pedigree.from_file(os.path.join(os.path.dirname(os.path.dirname(HERE)), "genlib.jl_amd", "data", "genea140.csv"))
 phi = ped.phi()
 np.save(os.path.join(HERE, "genea140_phi_oracle.npy"), phi)
 print("genea140:", phi.shape, float(phi.astype(np.float64).sum()))

@@ -310,34 +310,40 @@ def test_phi_mean_on_device(gen, oracle):
 
 
 def test_inbreeding_f_from_the_sweep(gen, oracle):
-    """gen.f(pedigree, IDs) (src/compute.jl:500-511) from one level sweep
-    over the parents + point lookups (genphi_result_entries) instead of the exponential
-    pairwise recursion."""
+    """gen.f(pedigree, IDs) (src/compute.jl:500-511) from ONE Float64 level sweep
+    over the parents + point lookups (genphi_result_entries) instead of the exponential pairwise
+    recursion -- bit-equal to the recursion (oracle.f restates :66-95 and :500-511 literally)."""
     ped = gen.genealogy(gen.geneaJi)
     assert gen.f(ped, [1]).tolist() == [GOLD["geneaJi"]["f_1"]]            # test/runtests.jl:47, exact
     assert gen.f(ped, [17]).tolist() == [GOLD["geneaJi"]["f_17"]]          # :48
     assert gen.f(ped, [1]).dtype == np.float32
     op = oracle.Pedigree.from_file(gen.geneaJi)
-    assert np.array_equal(gen.f(ped, ped.ind), op.f(ped.ind))              # every individual, exact (dyadic)
+    assert np.array_equal(gen.f(ped, ped.ind), op.f(ped.ind))              # every individual
     with pytest.raises(KeyError):
         gen.f(ped, [424242])
-    # genea140: bit-equal to the oracle's level sweep over the same parents, and within the
-    # Float32-per-level rounding of the exact pairwise recursion (SURVEY fact 5: <= ~3e-8)
+    # genea140, all 140 probands: bit-equal to the exact Float64 recursion rounded once (north-star
+    # tolerance 1e-12: the difference is exactly 0), where the Float32-per-level sweep is off by up to 3e-8
     ped = gen.genealogy(gen.genea140)
     op = oracle.Pedigree.from_file(gen.genea140)
     ids = gen.pro(ped)
     got = gen.f(ped, ids)
+    want = op.f(ids)
+    assert got.dtype == want.dtype == np.float32
+    assert np.array_equal(got, want), np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    assert np.count_nonzero(got) > 100
     pos = ped.positions(ids)
     fa, mo = ped.father[pos], ped.mother[pos]
-    both = (fa != 0) & (mo != 0)
-    parents = np.unique(np.concatenate([fa[both], mo[both]]))
-    sweep = op.phi(parents)
-    want = np.zeros(len(ids), dtype=np.float32)
-    want[both] = sweep[np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both])]
-    assert np.array_equal(got, want)
-    assert np.count_nonzero(got) > 0
-    exact = op.f(ids[:40])
-    assert np.max(np.abs(got[:40].astype(np.float64) - exact.astype(np.float64))) <= 4e-8
+    parents = np.unique(np.concatenate([fa, mo]))
+    sweep32 = gen.phi(ped, parents)[np.searchsorted(parents, fa), np.searchsorted(parents, mo)]
+    assert 0 < np.abs(sweep32.astype(np.float64) - want.astype(np.float64)).max() <= 4e-8      # what round 1 returned
+    # a random pedigree with one-parent individuals and overlapping generations
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(3000, 300, 9, skip_permille=120, seed=4)
+    mo = mo.copy(); mo[::17] = 0                                           # one-parent rows (father only)
+    ped2 = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    op2 = oracle.Pedigree(ind, fa, mo)
+    some = np.concatenate([pro[:60], ind[1500:1530]])
+    assert np.array_equal(gen.f(ped2, some), op2.f(some))
     # point lookups: any entry of a resident (sharded) result
     pl = gen.plan(ped)
     full = pl.compute()
@@ -463,3 +469,181 @@ def test_full_size_cfg4_properties(gen):
     d = np.concatenate([a[np.arange(64), 1000 + np.arange(64)], b[np.arange(64), 77_000 + np.arange(64)]])
     assert d.min() >= 0.5 and d.max() < 1.0 and a.min() >= 0.0 and a.max() < 1.0
     pl.close()
+
+
+def _merge(peds):
+    """Disjoint union of (ind, father, mother, sex, pro) pedigrees, IDs relabelled."""
+    ind, fa, mo, sex, pro, off = [], [], [], [], [], 0
+    for i, f, m, s, p in peds:
+        i, f, m, s, p = (np.asarray(x, dtype=np.int64) for x in (i, f, m, s, p))
+        rel = lambda a: np.where(a > 0, a + off, 0)                        # noqa: E731
+        ind.append(i + off); fa.append(rel(f)); mo.append(rel(m)); sex.append(s); pro.append(p + off)
+        off += int(i.max())
+    return tuple(np.concatenate(x) for x in (ind, fa, mo, sex, pro))
+
+
+def test_certified_rows_fast_path_and_mixed_levels(gen, oracle, monkeypatch):
+    """SPLIT levels run two kernels: sibling groups whose source rows all carry the exactness
+    certificate (entries 0 or >= 2^-27: every Float64 partial sum exact, so the reference's grouping
+    cannot matter) take level_split_fast_kernel, the others the grouping-exact level_split_kernel;
+    the split is made on the device per launch.  All of: certified only, uncertified only, mixed
+    (threshold raised by the test hook; really tiny kinships), 512- and 1024-thread variants, row
+    shards -- must equal the oracle bit for bit."""
+    from genlib_jl_amd import synth
+    base = synth.random_mating(6000, 700, 7, skip_permille=30)
+    tiny = synth.chain_two_lines(22)                                       # kinship 2^-45: no certificate
+    tiny2 = synth.chain_two_lines(40)
+    cases = [base, _merge([base, tiny, tiny2]), synth.random_mating(3000, 300, 12, skip_permille=100, seed=11)]
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")                      # no FULL kernel: every level is SPLIT
+    monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+    for ind, fa, mo, sex, pro in cases:
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        for cap in (8192, 1024):                                          # one / several column chunks
+            monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+            for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-9"}, {"GENPHI_CERT_MIN_EXP": "-4"},
+                        {"GENPHI_CERT_MIN_EXP": "-1"}, {"GENPHI_FAST_NT": "512"}, {"GENPHI_FAST_NT": "512", "GENPHI_CERT_MIN_EXP": "-5"},
+                        {"GENPHI_MAX_CPT": "8", "GENPHI_CERT_MIN_EXP": "-6"}):
+                for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_MAX_CPT"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                pl = gen.plan(ped, pro)
+                assert set(pl.step_modes()) == {1}
+                _assert_equal(pl.compute(), want)
+                n = len(want)
+                parts = [pl.compute(rows=r) for r in [(0, n // 3), (n // 3, n // 3 + 1), (n // 3 + 1, n)]]
+                _assert_equal(np.concatenate(parts, axis=0), want)
+                pl.close()
+    for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_MAX_CPT", "GENPHI_FULL_MAX_FLOATS",
+              "GENPHI_NO_SMALL", "GENPHI_LDS_CAP_FLOATS"):
+        monkeypatch.delenv(k, raising=False)
+    # genea140 (real pedigree, kinships down to 2^-35: some rows are not certified), default geometry
+    ped = gen.genealogy(gen.genea140)
+    gold = np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy"))
+    for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-12"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _assert_equal(gen.phi(ped), gold)
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+
+
+def test_graph_replay_survives_shard_changes_and_release(gen, oracle):
+    """A captured hipGraph bakes device pointers in; every reallocation (another shard, a larger
+    result) must retire it.  Sequence A, A, B, A, A with a larger shard B in between, then a
+    release of all device memory and a re-upload."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.deep_inbred(40, 40, 3)                   # 39 level steps: graphs are used (>= 8)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    pl = gen.plan(ped, pro)
+    A, B = (3, 11), (0, 40)
+    for r in (A, A, A, B, A, A, A, B, B, B, A):
+        _assert_equal(pl.compute(rows=r), want[r[0]:r[1]])
+    _assert_equal(pl.compute(), want)
+    pl.release_device()
+    for r in (A, A, A, None, None, None):
+        got = pl.compute(rows=r)
+        _assert_equal(got, want if r is None else want[r[0]:r[1]])
+    pl.release_device()
+    pl.release_device()                                                    # idempotent
+    _assert_equal(pl.compute(device=0), want)
+    pl.close()
+
+
+def test_wide_levels_block_assembly(gen, oracle, monkeypatch):
+    """WIDE steps (a source row does not fit in LDS; forced here by shrinking the LDS budget): the
+    level is assembled from row compaction (dragged x dragged, new x dragged), a transpose (dragged x
+    new) and a FULL / SPLIT sub-step on the compacted parent matrix (new x new) -- or the per-entry
+    kernel when the parents are too many as well.  Overlapping generations (most of a cut is dragged
+    along), a WIDE last step (proband-order delivery), row shards, certificates on and off."""
+    from genlib_jl_amd import synth
+    seen_nn = set()
+    for cap, fullmax, args, kw in [(3200, 8192, (16000, 400, 16), dict(skip_permille=600)),       # new x new by a FULL sub-step
+                                   (1500, 8192, (9000, 600, 10), dict(skip_permille=400)),
+                                   (1500, 0, (9000, 600, 10), dict(skip_permille=400)),
+                                   (700, 8192, (9000, 600, 10), dict(skip_permille=400, seed=5)),
+                                   (400, 8192, (4000, 900, 6), dict(skip_permille=150)),        # last step WIDE too
+                                   (256, 8192, (3000, 300, 12), dict(skip_permille=100, seed=11))]:
+        monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+        monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", str(fullmax))
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-5"}):
+            for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pl = gen.plan(ped, pro)
+            modes = pl.step_modes()
+            assert 2 in modes
+            seen_nn |= {pl.step_info(k)[3] for k in range(len(modes)) if modes[k] == 2}
+            _assert_equal(pl.compute(), want)
+            _assert_equal(pl.compute(kernel=1), want)
+            n = len(want)
+            parts = [pl.compute(rows=r) for r in [(0, 7), (7, n // 2), (n // 2, n)]]
+            _assert_equal(np.concatenate(parts, axis=0), want)
+            pl.close()
+    assert {0, 1, 3} <= seen_nn, seen_nn          # FULL, SPLIT and per-entry new x new blocks all exercised
+    for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_pairwise_phi_float64(gen, oracle):
+    """gen.phi(individual_i, individual_j) (src/compute.jl:66-95): Float64 kinship of a pair from one
+    Float64 level sweep.  Reference pins: test/runtests.jl:49 (phi(ped[1], ped[2]) == 0.37109375) and
+    :58-60 (two founders -> 0); everything else against the oracle's literal recursion, bit for bit
+    (tolerance of the north star: 1e-12; asserted: 0)."""
+    ped = gen.genealogy(gen.geneaJi)
+    assert gen.phi(ped[1], ped[2]) == GOLD["geneaJi"]["phi_pair_1_2"]
+    founders = gen.founder(ped)
+    assert gen.phi(ped[int(founders[0])], ped[int(founders[1])]) == 0.0
+    assert isinstance(gen.phi(ped[1], ped[2]), float)
+    op = oracle.Pedigree.from_file(gen.geneaJi)
+    for i in ped.ind:
+        for j in ped.ind[::3]:
+            assert gen.phi(ped[int(i)], ped[int(j)]) == op.phi_pair(int(i), int(j)), (i, j)
+    assert gen.phi(ped[1], ped[1]) == 0.5 + 0.5 * op.phi_pair(int(ped[1].father.ID), int(ped[1].mother.ID))
+    with pytest.raises(KeyError):
+        ped[424242]
+    assert ped[1].father.ID == int(ped.father[ped.positions([1])[0]]) and ped[int(founders[0])].father is None
+    # many pairs in one sweep through the C-ABI (genphi_phi_pairs), genea140
+    from genlib_jl_amd import _capi
+    ped = gen.genealogy(gen.genea140)
+    op = oracle.Pedigree.from_file(gen.genea140)
+    pro = gen.pro(ped)
+    rng = np.random.default_rng(1)
+    a = rng.choice(pro, 24); b = rng.choice(pro, 24)
+    a[3] = b[3]                                                            # a self pair
+    got = _capi.phi_pairs(ped.ind, ped.father, ped.mother, a, b)
+    want = np.array([op.phi_pair(int(x), int(y)) for x, y in zip(a, b)])
+    assert got.dtype == np.float64 and np.array_equal(got, want), np.abs(got - want).max()
+    assert np.count_nonzero(got) > 5
+    # the Float64 result of a plan: all rows, shards, and its Float32 delivery (one rounding)
+    sub = pro[:30]
+    pl = gen.plan(ped, sub)
+    pl.compute_device(storage64=True)
+    full = pl.result_to_host_f64()
+    want = np.array([[op.phi_pair(int(x), int(y)) for y in sub[:6]] for x in sub[:6]])
+    assert np.array_equal(full[:6, :6], want) and np.array_equal(full, full.T)
+    assert np.array_equal(pl.result_to_host(), full.astype(np.float32))
+    pl.compute_device(storage64=True, rows=(4, 9))
+    assert np.array_equal(pl.result_to_host_f64(), full[4:9])
+    assert np.array_equal(pl.result_entries([4, 8], [0, 29]), full[[4, 8], [0, 29]])
+    pl.compute_device()                                                    # back to the Float32 sweep on the same plan
+    _assert_equal(pl.result_to_host(), oracle.Pedigree.from_file(gen.genea140).phi(sub))
+    pl.close()
+
+
+def test_branching_then_phi(gen, oracle):
+    """SURVEY 8(f) row 2 through the GPU: pruning the pedigree to the probands' ancestors
+    (gen.branching, src/extract.jl:65-186) must not change gen.phi."""
+    ped = gen.genealogy(gen.genea140)
+    pro = gen.pro(ped)[10:60]
+    pruned = gen.branching(ped, pro=pro)
+    assert len(pruned) < len(ped)
+    _assert_equal(gen.phi(pruned, pro), gen.phi(ped, pro))
+    ped = gen.genealogy(gen.geneaJi)
+    _assert_equal(gen.phi(gen.branching(ped, pro=[1, 29]), [1, 29]), gen.phi(ped, [1, 29]))

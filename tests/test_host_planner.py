@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(os.path.dirname(HERE), "genlib.jl_amd", "data")      # the two bundled pedigrees (data files of the reference's tests)
 ROOT = os.path.dirname(HERE)
 
 
@@ -33,7 +34,7 @@ def _load(gen, path):
 
 @pytest.mark.parametrize("name", ["geneaJi.csv", "genea140.csv"])
 def test_genealogy_pro_founder_match_oracle(gen, oracle, name):
-    path = os.path.join(HERE, "golden", name)
+    path = os.path.join(DATA, name)
     ped = _load(gen, path)
     oped = oracle.Pedigree.from_file(path)
     assert np.array_equal(ped.ind, oped.ind)            # same rank order (stable depth sort)
@@ -57,10 +58,10 @@ def _check_levels(gen, oracle, ind, fa, mo, sex, pro):
 
 def test_levels_match_oracle_bundled(gen, oracle):
     for name in ["geneaJi.csv", "genea140.csv"]:
-        ind, fa, mo, sex = oracle.read_tsv(os.path.join(HERE, "golden", name))
+        ind, fa, mo, sex = oracle.read_tsv(os.path.join(DATA, name))
         _check_levels(gen, oracle, ind, fa, mo, sex, None if True else None)
-    ind, fa, mo, sex = oracle.read_tsv(os.path.join(HERE, "golden", "genea140.csv"))
-    ped = gen.genealogy(os.path.join(HERE, "golden", "genea140.csv"))
+    ind, fa, mo, sex = oracle.read_tsv(os.path.join(DATA, "genea140.csv"))
+    ped = gen.genealogy(os.path.join(DATA, "genea140.csv"))
     pro = gen.pro(ped)
     # explicit proband subsets, shuffled order, with duplicates and a non-leaf proband
     rng = np.random.default_rng(1)
@@ -145,7 +146,7 @@ def test_native_loader_matches_oracle_rank_order(gen, oracle, tmp_path):
     (src/create.jl:161-189) + stable depth sort (:196-227), against the oracle's restatement."""
     from genlib_jl_amd import synth, _capi
     for name in ("geneaJi.csv", "genea140.csv"):
-        path = os.path.join(HERE, "golden", name)
+        path = os.path.join(DATA, name)
         ind, fa, mo, sex = _capi.genealogy_read(path)
         op = oracle.Pedigree.from_file(path)
         assert np.array_equal(ind, op.ind) and np.array_equal(fa, op.father) and np.array_equal(mo, op.mother)

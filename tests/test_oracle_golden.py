@@ -7,12 +7,13 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(os.path.dirname(HERE), "genlib.jl_amd", "data")      # the two bundled pedigrees (data files of the reference's tests)
 GOLD = json.load(open(os.path.join(HERE, "golden", "reference_pinned.json")))
 
 
 def test_geneaJi_reference_pinned(oracle):
     g = GOLD["geneaJi"]
-    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "geneaJi.csv"))
+    ped = oracle.Pedigree.from_file(os.path.join(DATA, "geneaJi.csv"))
     assert ped.pro().tolist() == g["pro"]                                  # runtests.jl:41
     assert ped.founder().tolist() == g["founder"]                          # :42
     assert ped.f([1]).tolist() == [g["f_1"]]                               # :47
@@ -29,7 +30,7 @@ def test_geneaJi_reference_pinned(oracle):
 
 def test_geneaJi_branching_reference_pinned(oracle):
     """The reference's own checks of gen.branching (test/runtests.jl:69-74), on the oracle."""
-    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "geneaJi.csv"))
+    ped = oracle.Pedigree.from_file(os.path.join(DATA, "geneaJi.csv"))
     iso = oracle.Pedigree(*ped.branching(pro=[1]), sort=False)
     assert iso.founder().tolist() == [17, 19, 20, 25, 26]                  # :70
     iso = oracle.Pedigree(*ped.branching(ancestors=[13]), sort=False)
@@ -41,7 +42,7 @@ def test_geneaJi_branching_reference_pinned(oracle):
 
 def test_genea140_survey_derived(oracle):
     g = GOLD["genea140_survey_derived"]
-    ped = oracle.Pedigree.from_file(os.path.join(HERE, "golden", "genea140.csv"))
+    ped = oracle.Pedigree.from_file(os.path.join(DATA, "genea140.csv"))
     assert ped.n == g["n_individuals"]
     pro = ped.pro()
     assert len(pro) == g["n_probands"]
