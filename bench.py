@@ -30,12 +30,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 WORKLOADS = {
-    # name: (n_ind, n_pro, n_gen) of synth.random_mating, or a special tag
+    # name: (n_ind, n_pro, n_gen[, skip_permille]) of synth.random_mating, or a special tag
     "cfg4": (1_000_000, 100_000, 30),
+    # cfg4 with overlapping generations: 0.5 % of the parents come from generation g-2, so ancestors are
+    # reached at several distances and are dragged through the cuts (cuts up to 123k members, 80 % of a
+    # cut dragged along, B = 1.45 TB): the WIDE block-assembly levels.  Not a BASELINE.json config.
+    "cfg4o": (1_000_000, 100_000, 30, 5),
     "cfg3": (100_000, 10_000, 20),
     "cfg2": "genea140",
     "cfg5": "deep_inbred",
 }
+
+
+def measured_ceiling():
+    """GB/s this access pattern (whole rows, 16-byte accesses, 3 reads : 2 writes, non-temporal stores,
+    no reuse) moved in profiles/microbench/row_stream2.hip on an MI355X: parsed from the committed
+    output of that run (context for roofline.frac, never the headline)."""
+    path = os.path.join(ROOT, "profiles", "microbench", "out", "r02_row_stream2.out")
+    try:
+        for line in open(path):
+            if "3 reads : 2 writes, nt stores" in line and "1024 thr" in line:
+                return float(line.split()[-2]) * 1000.0, os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    return None, None
 
 
 def load_workload(name):
@@ -49,9 +67,10 @@ def load_workload(name):
         ind, fa, mo, sex, pro = synth.deep_inbred(200, 50, 3)
         desc = "deep consanguineous synthetic pedigree (1e4 individuals, 200 generations x 50, 3 sires/generation)"
     else:
-        ind, fa, mo, sex, pro = synth.random_mating(*w)
+        skip = w[3] if len(w) > 3 else 0
+        ind, fa, mo, sex, pro = synth.random_mating(w[0], w[1], w[2], skip_permille=skip)
         desc = (f"synthetic random-mating pedigree, {w[0]} individuals / {w[1]} probands / {w[2]} generations, "
-                f"SplitMix64 seed {synth.SEED}")
+                f"SplitMix64 seed {synth.SEED}" + (f", {skip} per mille of the parents from generation g-2" if skip else ""))
     ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
     return ped, pro, desc
 
@@ -143,6 +162,7 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the device-to-host copy of the end_to_end block")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -176,25 +196,39 @@ def main():
 
     import genlib_jl_amd as gen
     ped, pro, desc = load_workload(args.workload)
-    pl = gen.plan(ped, pro)
+    t_plan = time.perf_counter()
+    pl = gen.plan(ped, pro)                                  # genphi_plan_create: levelisation + flat index arrays (host)
+    plan_ms = (time.perf_counter() - t_plan) * 1e3
     sizes, both = pl.levels()
     n = pl.n_probands
     # final-level row shard of this rank (proband tiles across the GPUs; no collective)
     r0, r1 = shard_rows(n, rank, world)
     rows = (r0, r1) if world > 1 else None
+    empty_shard = world > 1 and r1 == r0                     # more ranks than probands: nothing to compute here
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows)
+    def compute(**kw):
+        return None if empty_shard else pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows, **kw)
+
+    # the first call also uploads the index arrays and allocates the level matrices and the result
+    t_first = time.perf_counter()
+    compute()
+    first_call_ms = (time.perf_counter() - t_first) * 1e3
+    for _ in range(max(args.warmup - 1, 0)):
+        compute()
     barrier()
     t0 = time.perf_counter()
     kernel_ms, level_ms, perm_ms = 0.0, None, 0.0
+    level_rows = None
     for _ in range(args.steps):
-        st = pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows, timing=True)
+        st = compute(timing=True)
+        if st is None:
+            continue
+        level_rows = [int(st.level_rows[k]) for k in range(st.n_steps)]
         kernel_ms += st.total_ms
         perm_ms += st.perm_ms
         lm = np.array(st.level_ms[:st.n_steps], dtype=np.float64)
@@ -213,16 +247,19 @@ def main():
         # roofline of the dominant kernel (the level kernel; every level step launches it once).
         # algorithmic bytes per launch = 4 (n_k^2 + n_{k+1}^2); for a sharded
         # final level the launch writes only its rows.
+        # a launch that computes only part of a level's rows (the sharded last level; the upper levels
+        # of a shard, restricted to its ancestors) is credited with the rows it wrote and the same
+        # share of the source matrix: byt = 4 (n_k^2 + n_{k+1}^2) * rows / n_{k+1}
         byt = [4.0 * (a * a + b * b) for a, b in zip(sizes[:-1], sizes[1:])]
-        if world > 1 and byt:
-            byt[-1] = 4.0 * (sizes[-2] ** 2 + (r1 - r0) * sizes[-1])
+        if level_rows is not None:
+            byt = [x * (min(r, b) / b if b else 1.0) for x, r, b in zip(byt, level_rows, sizes[1:])]
         lvl = (level_ms / K) if level_ms is not None and len(byt) else np.zeros(0)
         lvl_kernel = lvl.copy()
         if len(lvl_kernel):
             lvl_kernel[-1] -= perm_ms / K                 # the proband-order pass is a different kernel
         # the kernel that dominates the step: by accumulated time over the level steps of each kind
         modes = pl.step_modes()
-        names = {0: "level_full_kernel", 1: "level_split_kernel", 2: "level_half_kernel"}
+        names = {0: "level_full_kernel", 1: "level_split_fast_kernel", 2: "wide level (rows_compact_kernel + ...)"}
         by_kernel = {}
         for k, t in enumerate(lvl_kernel):
             small = k < len(lvl_kernel) - 1 and sizes[k] <= 128 and sizes[k + 1] <= 128 and args.kernel == 0
@@ -231,6 +268,33 @@ def main():
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else "level_split_kernel"
         tot_b, tot_ms = float(sum(byt)), float(lvl_kernel.sum())
         achieved = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        # end to end through the C-ABI: plan (host) + first call (upload, allocation,
+        # one sweep) ... + a sweep + the device-to-host copy of the N x N result.  Never `value`.
+        end_to_end = {"plan_ms": plan_ms, "first_call_ms": first_call_ms, "sweep_ms": ms_per_step}
+        if world == 1 and not args.no_d2h:
+            import psutil
+            need = n * n * 4
+            if psutil.virtual_memory().available > need + (16 << 30):
+                t0d = time.perf_counter()
+                host = pl.result_to_host()
+                end_to_end["d2h_ms"] = (time.perf_counter() - t0d) * 1e3
+                end_to_end["d2h_GBs"] = need / (end_to_end["d2h_ms"] * 1e-3) / 1e9
+                end_to_end["d2h_sample"] = "the whole N x N Float32 result into a pageable host array"
+                del host
+            else:
+                k = max(1, min(n, (4 << 30) // max(n * 4, 1)))
+                pl.compute_device(device=local_rank, kernel=args.kernel, rows=(0, k))
+                t0d = time.perf_counter()
+                host = pl.result_to_host()
+                dt = time.perf_counter() - t0d
+                end_to_end["d2h_ms"] = dt * 1e3 * n / k
+                end_to_end["d2h_GBs"] = k * n * 4 / dt / 1e9
+                end_to_end["d2h_sample"] = f"first {k} of {n} rows (host memory is short), scaled to N rows"
+                del host
+            tot = (plan_ms + ms_per_step + end_to_end["d2h_ms"]) * 1e-3
+            end_to_end["total_ms_plan_sweep_d2h"] = tot * 1e3
+            end_to_end["pairs_per_s"] = n * n / tot
+        ceiling, ceiling_src = measured_ceiling()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath):
@@ -242,9 +306,9 @@ def main():
             "metric": "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline",
             "value": value, "unit": "proband-pairs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "end_to_end": end_to_end,
             "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(sizes),
-                       "arithmetic": "Float64 accumulation over Float32 level matrices (the reference's contract)",
+                       "arithmetic": "Float64 accumulation over Float32 level matrices (the reference's contract)", "storage": "f32",
                        "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes / 1e9,
                        "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
                        "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,
@@ -257,7 +321,8 @@ def main():
                          # context, not the headline: what this access pattern (whole 96 KB rows, 16-byte
                          # accesses, 3 reads : 2 writes, no reuse) can move at all on this GPU, measured by
                          # profiles/microbench/row_stream.hip; and the rate of the REAL traffic when known
-                         "measured_ceiling_GBs": 5350.0,
+                         "measured_ceiling_GBs": ceiling, "measured_ceiling_source": ceiling_src,
+                         "traffic_source": f"profiles/traffic_{args.workload}.json (rocprofv3 PMC passes of this command; not re-collected by this run)" if traffic else None,
                          "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),

@@ -11,6 +11,7 @@ meaning, printed lines and error behaviour as the reference:
     phi = gen.phi(ped, verbose=True)       # src/compute.jl:233-304 -> float32 (N, N)
     gen.phi(ped[1], ped[2])                # src/compute.jl:66-95: pairwise, Float64 (one Float64 GPU sweep)
     gen.phiMean(phi)                       # src/compute.jl:454-459 (PhiPlan.phi_mean(): on the device)
+    K = gen.sparse_phi(ped); K[1, 2]       # src/compute.jl:321-447, :31-46; gen.phiMean(K) :467-472
     gen.f(ped, [1])                        # src/compute.jl:500-511, from one Float64 GPU sweep over the parents
     gen.branching(ped, pro=[1])            # src/extract.jl:65-186, native pruning (csrc/loader.cpp)
 
@@ -22,7 +23,7 @@ import os
 import numpy as np
 
 from . import _capi
-from ._capi import PhiPlan, GenphiDeviceError, GenphiLibraryMissing  # noqa: F401
+from ._capi import PhiPlan, KinshipMatrix, GenphiDeviceError, GenphiLibraryMissing  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
@@ -265,6 +266,16 @@ def branching(pedigree, pro=None, ancestors=None):
                                      pro=pro, ancestors=ancestors))
 
 
+def sparse_phi(pedigree, probandIDs=None, device=None):
+    """gen.sparse_phi(pedigree, probandIDs = pro(pedigree)) (src/compute.jl:321-447): the reference's
+    queue-driven kinship algorithm, returning a KinshipMatrix indexed by proband IDs (`K[1, 2]`,
+    `repr(K)` = the reference's `show` line, `gen.phiMean(K)`).  Computed on the GPU one depth at a
+    time on a dense active matrix (csrc/sparse_phi.hip); values, lookup behaviour and the number of
+    stored entries are the reference's.  KeyError for an unknown proband ID."""
+    probandIDs = pro(pedigree) if probandIDs is None else np.asarray(probandIDs, dtype=np.int64)
+    return KinshipMatrix(pedigree.ind, pedigree.father, pedigree.mother, probandIDs, device=device)
+
+
 def phiMean(phi_matrix):
     """gen.phiMean(::Matrix{Float32}) (src/compute.jl:454-459): mean off-diagonal kinship of a host
     matrix, accumulated in float32 like the reference.  numpy's float32 pairwise summation blocks
@@ -272,6 +283,9 @@ def phiMean(phi_matrix):
     Float32; exact whenever the sums are exact, e.g. 0.171875 on geneaJi, test/runtests.jl:53).
     `PhiPlan.phi_mean()` reduces the RESIDENT matrix on the device instead (Float64 accumulation,
     one rounding; no 40 GB device-to-host copy at N = 1e5)."""
+    if isinstance(phi_matrix, KinshipMatrix):            # phiMean(::KinshipMatrix), src/compute.jl:467-472
+        nr, _, total, diagonal = phi_matrix.info()
+        return np.float32((total - diagonal) / (nr * (nr - 1) / 2))
     m = np.asarray(phi_matrix, dtype=np.float32)
     total = np.float32(m.sum(dtype=np.float32))
     diagonal = np.float32(np.diagonal(m).sum(dtype=np.float32))

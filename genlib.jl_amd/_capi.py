@@ -35,7 +35,7 @@ class GenphiOpts(C.Structure):
 class GenphiStats(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("timed", C.c_int32), ("total_ms", C.c_double),
                 ("final_ms", C.c_double), ("perm_ms", C.c_double), ("algorithmic_bytes", C.c_double), ("max_cut", C.c_int64),
-                ("level_ms", C.c_float * GENPHI_MAX_STAT_LEVELS)]
+                ("level_ms", C.c_float * GENPHI_MAX_STAT_LEVELS), ("level_rows", C.c_int64 * GENPHI_MAX_STAT_LEVELS)]
 
 
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
-    "genphi_version",
+    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
 ]
 
 _lib = None
@@ -108,6 +108,16 @@ def lib():
         L.genphi_plan_release_device.restype = C.c_int
         L.genphi_plan_destroy.argtypes = [C.c_void_p]
         L.genphi_plan_destroy.restype = None
+        L.genphi_sparse_phi.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.c_int32, C.POINTER(C.c_void_p)]
+        L.genphi_sparse_phi.restype = C.c_int
+        L.genphi_sparse_info.argtypes = [C.c_void_p, _I64P, _I64P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.genphi_sparse_info.restype = C.c_int
+        L.genphi_sparse_get.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double)]
+        L.genphi_sparse_get.restype = C.c_int
+        L.genphi_sparse_entries.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, _F32P]
+        L.genphi_sparse_entries.restype = C.c_int64
+        L.genphi_sparse_destroy.argtypes = [C.c_void_p]
+        L.genphi_sparse_destroy.restype = None
         L.genphi_last_error.restype = C.c_char_p
         L.genphi_version.restype = C.c_char_p
         _lib = L
@@ -336,3 +346,53 @@ def phi_pairs(ind, father, mother, id_i, id_j, device=None):
     if rc:
         _raise(rc)
     return out
+
+
+class KinshipMatrix:
+    """What gen.sparse_phi returns (src/compute.jl:31-46): kinships of the probands, accessed by IDs."""
+
+    def __init__(self, ind, father, mother, pro_ids, device=None):
+        L = lib()
+        ind, father, mother, pro_ids = _i64(ind), _i64(father), _i64(mother), _i64(pro_ids)
+        h = C.c_void_p()
+        rc = L.genphi_sparse_phi(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P),
+                                 len(pro_ids), pro_ids.ctypes.data_as(_I64P), -1 if device is None else int(device), C.byref(h))
+        if rc:
+            _raise(rc)
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().genphi_sparse_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        """(rows, stored entries, Float64 sum of all stored values, Float64 sum of the self kinships)."""
+        nr, nz, sa, sd = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        rc = lib().genphi_sparse_info(self._h, C.byref(nr), C.byref(nz), C.byref(sa), C.byref(sd))
+        if rc:
+            _raise(rc)
+        return nr.value, nz.value, sa.value, sd.value
+
+    def get(self, id1, id2):
+        id1, id2 = _i64(np.atleast_1d(id1)), _i64(np.atleast_1d(id2))
+        out = np.empty(len(id1), dtype=np.float64)
+        rc = lib().genphi_sparse_get(self._h, len(id1), id1.ctypes.data_as(_I64P), id2.ctypes.data_as(_I64P),
+                                     out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc:
+            _raise(rc)
+        return out
+
+    def __getitem__(self, ids):
+        """phi[ID1, ID2] (getindex, src/compute.jl:36-40); KeyError for an ID that is not a proband."""
+        return float(self.get([ids[0]], [ids[1]])[0])
+
+    def entries(self):
+        n = lib().genphi_sparse_entries(self._h, 0, None, None, None)
+        r, c, v = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float32)
+        lib().genphi_sparse_entries(self._h, n, r.ctypes.data_as(_I64P), c.ctypes.data_as(_I64P), v.ctypes.data_as(_F32P))
+        return r, c, v
+
+    def __repr__(self):
+        nr, nz, _, _ = self.info()
+        return f"{nr}×{nr} KinshipMatrix with {nz} stored entries."          # Base.show, src/compute.jl:42-46

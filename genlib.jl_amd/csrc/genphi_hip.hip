@@ -346,9 +346,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
     if (n_items == 0) return;                             // nothing uncertified in this launch
-    // hand-over slots (item, group, A source, position in the group list): thread 0 resolves the
-    // item it has drawn (list indirection, group descriptor) off the critical path
-    int *slot = reinterpret_cast<int *>(lds + p.slot_off);
+    int *slot = reinterpret_cast<int *>(lds + p.slot_off);   // queue hand-over slots (thread 0 draws one item ahead)
     if (threadIdx.x == 0) {
         slot[0] = draw();
         slot[1] = draw();
@@ -630,9 +628,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
     if (n_items == 0) return;                             // no certified group in this launch
-    // hand-over slots (item, group, A source, position in the group list): thread 0 resolves the
-    // item it has drawn (list indirection, group descriptor) off the critical path
-    int *slot = reinterpret_cast<int *>(lds + p.slot_off);
+    int *slot = reinterpret_cast<int *>(lds + p.slot_off);   // queue hand-over slots (thread 0 draws one item ahead)
     if (threadIdx.x == 0) {
         slot[0] = draw();
         slot[1] = draw();
@@ -1908,11 +1904,18 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
             // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
             // group list) -> glist_s / gcnt[3]: decided on the device, per launch
             int *glist_f = p->d_glist, *glist_s = p->d_glist + (static_cast<size_t>(p->plan.max_cut) + 64) / 64 * 64;
-            hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
-                               static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
-            hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp_s,
-                               static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
-                               gcnt + 2);
+            int *gcnt_s = gcnt;                                               // [1] = groups of the grouping-exact kernel
+            if (dg.span_s) {
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
+                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp_s,
+                                   static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
+                                   gcnt + 2);
+                gcnt_s = gcnt + 2;
+            } else {                                                          // both kernels walk the same group list: one pass
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
+                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, glist_s, gcnt);
+            }
             HIP_TRY(hipGetLastError());
             f.glist = glist_f; f.gcnt = gcnt;
             f.chunk_magic = chunk_magic_for(f_chunks);
@@ -1925,7 +1928,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
             HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue)
                                : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue));
             a.zero_row = 0;                                                   // the fast launch wrote the "none" row
-            a.glist = glist_s; a.gcnt = gcnt + 2;
+            a.glist = glist_s; a.gcnt = gcnt_s;
         }
         // ---- the other groups (all of them without certificates): level_split_kernel ----
         a.slot_off = static_cast<int>(lds_stage_s / sizeof(float));
@@ -2393,6 +2396,15 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         if (rc) return rc;
         std::memcpy(p->eager_key, key, sizeof(key));
         p->eager_valid = true;
+    }
+    if (stats) {
+        for (int s = 0; s < n_steps && s < GENPHI_MAX_STAT_LEVELS; ++s) {
+            const LevelStep &st = pl.steps[s];
+            int64_t rows = st.n;
+            if (s == n_steps - 1) rows = need_perm ? st.n : n_rows;
+            else if (st.mode != genphi::kModeWide && p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step) rows = p->sh_steps[s].n_rows;
+            stats->level_rows[s] = rows;
+        }
     }
     if (timing && n_steps == 0) HIP_TRY(hipEventRecord(p->events[1], p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));

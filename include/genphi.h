@@ -65,6 +65,8 @@ typedef struct genphi_stats {
     double  algorithmic_bytes;       /* 4 * sum_k (n_k^2 + n_{k+1}^2), SURVEY.md 8(d)       */
     int64_t max_cut;                 /* largest cut size                                    */
     float   level_ms[GENPHI_MAX_STAT_LEVELS]; /* per level step (first n_steps entries)     */
+    int64_t level_rows[GENPHI_MAX_STAT_LEVELS]; /* output rows each level step computed (a row shard
+                                        computes, above the last level, only the rows it descends from) */
 } genphi_stats;
 
 /* Replaces the host prologue of phi(): levelisation by parent steps and the cut sets
@@ -184,6 +186,30 @@ int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, c
  * uploads again, on the same or on another device (opts->device).  The reference has no
  * counterpart (its matrices are garbage-collected Julia arrays, src/compute.jl:291,301).      */
 int genphi_plan_release_device(genphi_plan *plan);
+
+/* ---- gen.sparse_phi / KinshipMatrix (src/compute.jl:321-447, :31-46, :467-472) -------------------
+ * The reference's second kinship algorithm: individuals are processed one at a time in queue order,
+ * each kinship is RN32(phi[father, j]/2 + phi[mother, j]/2), parents are dropped when their children
+ * are done, and the result is a dictionary of the probands' non-zero kinships keyed by rank.  Here the
+ * queue is simulated on the host (integers only) and all individuals of one depth are computed by two
+ * kernel launches on a dense "active" matrix in HBM (csrc/sparse_phi.hip).  Values, getindex
+ * semantics (incl. the reference's (earlier, later) vs (smaller, larger rank) key behaviour), the
+ * number of stored entries `show` prints and phiMean's sums are those of the reference.
+ *   genphi_sparse_phi      sparse_phi(pedigree, probandIDs); pedigree in rank order as for
+ *                          genphi_plan_create; runs on the GPU (no CPU fallback)
+ *   genphi_sparse_info     n_rows x n_rows KinshipMatrix with n_stored entries; Float64 sums of all
+ *                          stored values and of the self kinships (phiMean = (all - diag) / (n (n-1) / 2))
+ *   genphi_sparse_get      getindex(phi, ID1, ID2) for n pairs; an ID that is not a proband ->
+ *                          GENPHI_ERR_UNKNOWN_ID (KeyError in the reference)
+ *   genphi_sparse_entries  every stored entry as (row rank, column rank, value); returns their number
+ *                          (the arrays may be NULL / cap 0 to ask for it)                               */
+typedef struct genphi_sparse genphi_sparse;
+int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                      int64_t n_pro, const int64_t *pro_ids, int32_t device, genphi_sparse **out);
+int genphi_sparse_info(const genphi_sparse *h, int64_t *n_rows, int64_t *n_stored, double *sum_all, double *sum_diag);
+int genphi_sparse_get(const genphi_sparse *h, int64_t n, const int64_t *id1, const int64_t *id2, double *out);
+int64_t genphi_sparse_entries(const genphi_sparse *h, int64_t cap, int64_t *row_rank, int64_t *col_rank, float *val);
+void genphi_sparse_destroy(genphi_sparse *h);
 
 /* Frees host and device memory of the plan (NULL is allowed). */
 void genphi_plan_destroy(genphi_plan *plan);

@@ -17,12 +17,13 @@ _F32P = C.POINTER(C.c_float)
 
 
 def build():
-    """Compile liboracle.so with gcc (idempotent)."""
-    so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "genphi_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
-    return so
+    """Compile liboracle.so (gcc) and libsparse_oracle.so (g++) (idempotent)."""
+    for name, srcname in (("libsparse_oracle.so", "sparse_oracle.cpp"), ("liboracle.so", "genphi_oracle.c")):
+        so = os.path.join(_HERE, name)
+        src = os.path.join(_HERE, srcname)
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", name])
+    return os.path.join(_HERE, "liboracle.so")
 
 
 def lib():
@@ -241,3 +242,87 @@ def phi_mean(phi):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+_SLIB = None
+
+
+def _slib():
+    global _SLIB
+    if _SLIB is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libsparse_oracle.so"))
+        L.sparse_oracle_create.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P]
+        L.sparse_oracle_create.restype = C.c_void_p
+        L.sparse_oracle_free.argtypes = [C.c_void_p]
+        L.sparse_oracle_free.restype = None
+        L.sparse_oracle_get.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.sparse_oracle_get.restype = C.c_double
+        L.sparse_oracle_info.argtypes = [C.c_void_p, _I64P, _I64P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.sparse_oracle_info.restype = None
+        L.sparse_oracle_order.argtypes = [C.c_void_p, _I64P, C.c_int64]
+        L.sparse_oracle_order.restype = C.c_int64
+        L.sparse_oracle_entries.argtypes = [C.c_void_p, _I64P, _I64P, _F32P, C.c_int64]
+        L.sparse_oracle_entries.restype = C.c_int64
+        _SLIB = L
+    return _SLIB
+
+
+class SparsePhi:
+    """sparse_phi(pedigree, probandIDs) of the reference (src/compute.jl:321-447), restated literally in
+    oracle/sparse_oracle.cpp: the KinshipMatrix it returns."""
+
+    def __init__(self, ped, pro=None):
+        pro = ped.pro() if pro is None else np.asarray(pro, dtype=np.int64)
+        self.pro = _i64(pro)
+        self._h = _slib().sparse_oracle_create(len(ped.ind), _p(ped.ind), _p(ped.father), _p(ped.mother), len(self.pro), _p(self.pro))
+        if not self._h:
+            raise KeyError("unknown proband ID")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _slib().sparse_oracle_free(self._h)
+            self._h = None
+
+    def __getitem__(self, ids):
+        v = _slib().sparse_oracle_get(self._h, int(ids[0]), int(ids[1]))
+        if v < 0:
+            raise KeyError(ids)
+        return v
+
+    def matrix(self):
+        """getindex for every pair of probands (float32; what a user sees through ϕ[ID1, ID2])."""
+        n = len(self.pro)
+        out = np.zeros((n, n), dtype=np.float32)
+        for a in range(n):
+            for b in range(n):
+                out[a, b] = self[(self.pro[a], self.pro[b])]
+        return out
+
+    def info(self):
+        """(rows, stored entries, sum of all stored values, sum of the diagonal values)."""
+        nr, nz = C.c_int64(), C.c_int64()
+        sa, sd = C.c_double(), C.c_double()
+        _slib().sparse_oracle_info(self._h, C.byref(nr), C.byref(nz), C.byref(sa), C.byref(sd))
+        return nr.value, nz.value, sa.value, sd.value
+
+    def show(self):
+        nr, nz, _, _ = self.info()
+        return f"{nr}×{nr} KinshipMatrix with {nz} stored entries."
+
+    def phi_mean(self):
+        """phiMean(::KinshipMatrix) (src/compute.jl:467-472), sums in Float64."""
+        nr, _, sa, sd = self.info()
+        return np.float32((sa - sd) / (nr * (nr - 1) / 2))
+
+    def order(self):
+        cap = 1 << 22
+        buf = np.zeros(cap, dtype=np.int64)
+        n = _slib().sparse_oracle_order(self._h, _p(buf), cap)
+        return buf[:n].copy()
+
+    def entries(self):
+        cap = _slib().sparse_oracle_entries(self._h, None, None, None, 0)
+        r, c, v = np.zeros(cap, np.int64), np.zeros(cap, np.int64), np.zeros(cap, np.float32)
+        _slib().sparse_oracle_entries(self._h, _p(r), _p(c), v.ctypes.data_as(_F32P), cap)
+        return r, c, v

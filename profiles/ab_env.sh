@@ -5,7 +5,7 @@
 WL=$1; shift
 for rep in 1 2 3; do
   for v in "$@"; do
-    env $v timeout -k 10 300 python bench.py --workload "$WL" --no-cpu-baseline > /tmp/ab.json 2> /tmp/ab.err || { echo "fail [$v]"; tail -3 /tmp/ab.err; }
+    env $v timeout -k 10 300 python bench.py --workload "$WL" --no-cpu-baseline --no-d2h > /tmp/ab.json 2> /tmp/ab.err || { echo "fail [$v]"; tail -3 /tmp/ab.err; }
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json")); l = d["config"]["level_ms"]

@@ -6,7 +6,7 @@ cp genlib.jl_amd/lib/libgenphi.so /tmp/keep.so
 for rep in 1 2 3; do
   for v in "$A" "$B"; do
     cp "$v" genlib.jl_amd/lib/libgenphi.so
-    timeout -k 10 200 python bench.py --workload "$WL" --no-cpu-baseline > /tmp/ab.json 2> /tmp/ab.err || { echo "fail $v"; tail -3 /tmp/ab.err; }
+    timeout -k 10 200 python bench.py --workload "$WL" --no-cpu-baseline --no-d2h > /tmp/ab.json 2> /tmp/ab.err || { echo "fail $v"; tail -3 /tmp/ab.err; }
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json")); l = d["config"]["level_ms"]

@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r01}; WL=${2:-cfg4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${WL}; rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --workload "$WL" --steps 2 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --workload "$WL" --steps 2 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline --no-d2h > "$OUT/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --workload "$WL" --steps 2 --warmup 0 --no-cpu-baseline --no-d2h > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --workload "$WL" --steps 2 --warmup 0 --no-cpu-baseline --no-d2h > "$OUT/pmc_write.log" 2>&1
 grep '^{' "$OUT/kt.log" | tail -1 | cut -c1-400

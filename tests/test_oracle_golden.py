@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = os.path.join(os.path.dirname(HERE), "genlib.jl_amd", "data")      # the two bundled pedigrees (data files of the reference's tests)
@@ -88,3 +89,18 @@ def test_oracle_edge_cases(oracle):
     import pytest
     with pytest.raises(KeyError):
         ped.phi([99])
+
+
+def test_sparse_phi_oracle_reproduces_the_reference_pins(oracle):
+    """test/runtests.jl:54-57 on geneaJi: phiMean(sparse_phi) == 0.171875, [1, 2] == 0.37109375 and
+    the `show` line "3×3 KinshipMatrix with 6 stored entries." -- the literal restatement of
+    src/compute.jl:321-447 in oracle/sparse_oracle.cpp gives exactly these."""
+    ped = oracle.Pedigree.from_file(os.path.join(DATA, "geneaJi.csv"))
+    K = oracle.SparsePhi(ped)
+    assert float(K.phi_mean()) == 0.171875
+    assert K[(1, 2)] == 0.37109375
+    assert K.show() == "3×3 KinshipMatrix with 6 stored entries."
+    # and on this pedigree the sparse and the dense algorithm agree entry for entry (runtests.jl:54)
+    assert np.array_equal(K.matrix(), ped.phi())
+    with pytest.raises(KeyError):
+        K[(1, 17)]                                       # 17 is not a proband
