@@ -154,6 +154,48 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits):
+    """N > 1 with storage-sharded level matrices: every rank holds a column panel of every level and
+    the ranks exchange parent columns before every level step (genlib_jl_amd/distributed.py)."""
+    import torch
+    from genlib_jl_amd import _capi, distributed as gdist
+    dev = torch.device("cuda", local_rank)
+    pl = _capi.PanelPlan(ped.ind, ped.father, ped.mother, np.asarray(pro, dtype=np.int64), rank, world)
+    n = pl.n_probands
+    for _ in range(max(args.warmup, 1)):
+        sent = gdist.panel_sweep(pl, dist, dev)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sent = gdist.panel_sweep(pl, dist, dev)
+    dist.barrier(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tt = torch.tensor([wall, float(sent)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    wall = float(tt[0].item())
+    if rank == 0:
+        K = args.steps
+        B = sum(4.0 * (a * a + b * b) for a, b in zip(cut_sizes[:-1], cut_sizes[1:]))
+        achieved = B / (wall / K) / 1e9
+        print(json.dumps({
+            "metric": "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline",
+            "value": n * n / (wall / K), "unit": "proband-pairs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(cut_sizes), "storage": "f32",
+                       "parallelism": f"column panels x{world}: every level storage-sharded, one all-to-all of parent columns per level step",
+                       "why_exchange": "forced" if fits else "two level matrices do not fit one GPU",
+                       "exchange_bytes_sent_per_rank_max": float(tt[1].item()),
+                       "panel_device_bytes": pl.device_bytes, "max_cut": max(cut_sizes)},
+            "roofline": {"bound": "hbm", "kernel": "panel_level_kernel (capacity path: per-entry gathers)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS / world, "traffic": None,
+                         "note": "achieved = algorithmic bytes of the whole job / time; frac is per GPU"},
+        }), flush=True)
+    pl.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +209,10 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N > 1: storage-sharded levels (column panels) with an all-to-all before every level step, "
+                         "instead of replicated levels; taken automatically when the level matrices do not fit one GPU "
+                         "(also GENPHI_FORCE_EXCHANGE=1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing: plan + shard + barrier + max-reduce, no compute")
     args = ap.parse_args()
@@ -196,6 +242,14 @@ def main():
 
     import genlib_jl_amd as gen
     ped, pro, desc = load_workload(args.workload)
+    if world > 1:
+        from genlib_jl_amd import distributed as gdist
+        probe = gen.plan(ped, pro)
+        cut_sizes = probe.levels()[0]
+        probe.close()
+        fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0])
+        if args.exchange or os.environ.get("GENPHI_FORCE_EXCHANGE") == "1" or not fits:
+            return run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits)
     t_plan = time.perf_counter()
     pl = gen.plan(ped, pro)                                  # genphi_plan_create: levelisation + flat index arrays (host)
     plan_ms = (time.perf_counter() - t_plan) * 1e3

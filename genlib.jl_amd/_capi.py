@@ -47,6 +47,9 @@ EXPORTED_SYMBOLS = [
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
     "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
+    "genphi_panel_create", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
+    "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_result_to_host",
+    "genphi_panel_destroy",
 ]
 
 _lib = None
@@ -118,6 +121,28 @@ def lib():
         L.genphi_sparse_entries.restype = C.c_int64
         L.genphi_sparse_destroy.argtypes = [C.c_void_p]
         L.genphi_sparse_destroy.restype = None
+        L.genphi_panel_create.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.genphi_panel_create.restype = C.c_int
+        L.genphi_panel_n_steps.argtypes = [C.c_void_p]
+        L.genphi_panel_n_steps.restype = C.c_int64
+        L.genphi_panel_n_probands.argtypes = [C.c_void_p]
+        L.genphi_panel_n_probands.restype = C.c_int64
+        L.genphi_panel_result_rows.argtypes = [C.c_void_p, _I64P, _I64P]
+        L.genphi_panel_result_rows.restype = C.c_int
+        L.genphi_panel_exchange_counts.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P]
+        L.genphi_panel_exchange_counts.restype = C.c_int
+        L.genphi_panel_device_bytes.argtypes = [C.c_void_p]
+        L.genphi_panel_device_bytes.restype = C.c_double
+        L.genphi_panel_begin.argtypes = [C.c_void_p, C.c_int32]
+        L.genphi_panel_begin.restype = C.c_int
+        L.genphi_panel_pack.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.genphi_panel_pack.restype = C.c_int
+        L.genphi_panel_compute.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.genphi_panel_compute.restype = C.c_int
+        L.genphi_panel_result_to_host.argtypes = [C.c_void_p, _F32P]
+        L.genphi_panel_result_to_host.restype = C.c_int
+        L.genphi_panel_destroy.argtypes = [C.c_void_p]
+        L.genphi_panel_destroy.restype = None
         L.genphi_last_error.restype = C.c_char_p
         L.genphi_version.restype = C.c_char_p
         _lib = L
@@ -396,3 +421,79 @@ class KinshipMatrix:
     def __repr__(self):
         nr, nz, _, _ = self.info()
         return f"{nr}×{nr} KinshipMatrix with {nz} stored entries."          # Base.show, src/compute.jl:42-46
+
+
+class PanelPlan:
+    """Storage-sharded gen.phi of one rank (column panels + exchange; include/genphi.h, csrc/panel_phi.hip)."""
+
+    def __init__(self, ind, father, mother, pro_ids, rank, world):
+        L = lib()
+        ind, father, mother, pro_ids = _i64(ind), _i64(father), _i64(mother), _i64(pro_ids)
+        h = C.c_void_p()
+        rc = L.genphi_panel_create(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P),
+                                   len(pro_ids), pro_ids.ctypes.data_as(_I64P), int(rank), int(world), C.byref(h))
+        if rc:
+            _raise(rc)
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().genphi_panel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_steps(self):
+        return int(lib().genphi_panel_n_steps(self._h))
+
+    @property
+    def n_probands(self):
+        return int(lib().genphi_panel_n_probands(self._h))
+
+    @property
+    def device_bytes(self):
+        return float(lib().genphi_panel_device_bytes(self._h))
+
+    def result_rows(self):
+        a, b = C.c_int64(), C.c_int64()
+        rc = lib().genphi_panel_result_rows(self._h, C.byref(a), C.byref(b))
+        if rc:
+            _raise(rc)
+        return a.value, b.value
+
+    def exchange_counts(self, step):
+        """(columns to send per rank, columns to receive per rank, floats per column) before level step `step`."""
+        s, r = np.zeros(self.world, np.int64), np.zeros(self.world, np.int64)
+        f = C.c_int64()
+        rc = lib().genphi_panel_exchange_counts(self._h, int(step), s.ctypes.data_as(_I64P), r.ctypes.data_as(_I64P), C.byref(f))
+        if rc:
+            _raise(rc)
+        return s, r, f.value
+
+    def begin(self, device=None):
+        rc = lib().genphi_panel_begin(self._h, -1 if device is None else int(device))
+        if rc:
+            _raise(rc)
+
+    def pack(self, step, d_send_ptr):
+        rc = lib().genphi_panel_pack(self._h, int(step), C.c_void_p(d_send_ptr))
+        if rc:
+            _raise(rc)
+
+    def compute(self, step, d_recv_ptr):
+        rc = lib().genphi_panel_compute(self._h, int(step), C.c_void_p(d_recv_ptr))
+        if rc:
+            _raise(rc)
+
+    def result_to_host(self):
+        r0, nr = self.result_rows()
+        out = np.empty((nr, self.n_probands), dtype=np.float32)
+        rc = lib().genphi_panel_result_to_host(self._h, out.ctypes.data_as(_F32P))
+        if rc:
+            _raise(rc)
+        return out

@@ -843,24 +843,31 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
                     const int *__restrict__ idx, int m, float *__restrict__ out, long long ld_out, int *__restrict__ cert_out,
                     unsigned cert_thresh)
 {
+    constexpr int U = 8;                                       // elements per thread, all loads in flight before the first use
     const int4 d = rowdesc[blockIdx.x];
     const float *ra = psi + (long long)d.x * ld_prev;
     const float *rb = psi + (long long)d.y * ld_prev;
     float *o = out + (long long)d.z * ld_out;
     const double sc = d.w == 0 ? 1.0 : 0.5;
-    const int k0 = blockIdx.y * 2048;
-    const int k1 = min(k0 + 2048, m);
+    const int k0 = blockIdx.y * (256 * U) + threadIdx.x;
+    int q[U];
+    float a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = idx[min(k0 + u * 256, m - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = ra[q[u]];
+    const bool two = d.y != none;                              // uniform: single-source rows do not stream the zero row
+    if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = rb[q[u]];
+    }
     unsigned ck = 0xffffffffu;
-    if (d.y == none) {
-        for (int k = k0 + threadIdx.x; k < k1; k += 256) {
-            const float v = static_cast<float>(static_cast<double>(ra[idx[k]]) * sc);
-            ck = min(ck, cert_key(v));
-            __builtin_nontemporal_store(v, o + k);
-        }
-    } else {
-        for (int k = k0 + threadIdx.x; k < k1; k += 256) {
-            const int q = idx[k];
-            const float v = static_cast<float>((static_cast<double>(ra[q]) + static_cast<double>(rb[q])) * sc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * 256;
+        const float v = two ? static_cast<float>((static_cast<double>(a[u]) + static_cast<double>(b[u])) * sc)
+                            : static_cast<float>(static_cast<double>(a[u]) * sc);
+        if (k < m) {
             ck = min(ck, cert_key(v));
             __builtin_nontemporal_store(v, o + k);
         }
@@ -870,20 +877,22 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
 
 // dst[c][dst_col0 + r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS, both sides
 // coalesced): the dragged x new block from the new x dragged block.  Flags the certificate of every
-// destination row that receives an uncertified value.
+// destination row that receives an uncertified value.  (128 x 128 tiles -- 512-byte runs on both
+// sides, 66 KB of LDS -- were measured 13 % slower on cfg4o: two workgroups per CU hide less latency.)
+constexpr int kTT = 64;
 __global__ void __launch_bounds__(256)
 transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows, int cols, float *__restrict__ dst,
                        long long ld_dst, int dst_col0, int *__restrict__ cert_out, unsigned cert_thresh)
 {
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    __shared__ float tile[kTT][kTT + 1];
+    const int r0 = blockIdx.y * kTT, c0 = blockIdx.x * kTT;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = ty; k < 64; k += 4) {
+    for (int k = ty; k < kTT; k += 4) {
         const int r = r0 + k, c = c0 + tx;
         tile[k][tx] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.f;
     }
     __syncthreads();
-    for (int k = ty; k < 64; k += 4) {
+    for (int k = ty; k < kTT; k += 4) {
         const int c = c0 + k, r = r0 + tx;
         if (c < cols && r < rows) {
             const float v = tile[tx][k];
@@ -1969,7 +1978,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     const bool nn_naive = s.nn_naive || s.nn.empty();
     const int rows_1 = nn_naive ? nd : n;                 // (naive fallback: the new rows come whole from the per-entry kernel)
     if (nd > 0 && rows_1 > 0) {
-        dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));
+        dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));      // 256 threads x 8 elements
         hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
                            d.rowdesc, d.srcA, nd, out, static_cast<long long>(s.ld), cert_out, thr);
         HIP_TRY(hipGetLastError());
@@ -2014,7 +2023,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         }
         // 4. dragged x new = (new x dragged)^T
         if (nd > 0) {
-            dim3 gt(static_cast<unsigned>((nd + 63) / 64), static_cast<unsigned>((n_new + 63) / 64));
+            dim3 gt(static_cast<unsigned>((nd + kTT - 1) / kTT), static_cast<unsigned>((n_new + kTT - 1) / kTT));
             hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(nd) * s.ld,
                                static_cast<long long>(s.ld), n_new, nd, out, static_cast<long long>(s.ld), nd, cert_out, thr);
             HIP_TRY(hipGetLastError());

@@ -77,6 +77,7 @@ private:
 
 int mode_for(int64_t n_prev, const PlanOptions &opt)
 {
+    if (opt.indices_only) return kModeFull;
     const int64_t lds_row = (n_prev + 1 + 3) / 4 * 4;
     if (2 * lds_row <= opt.lds_cap_floats && lds_row <= opt.full_max_floats) return kModeFull;
     if (lds_row <= opt.lds_cap_floats && n_prev < 65535) return kModeSplit;
@@ -344,6 +345,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         }
         st.n_dragged = dragged;
         plan.both_counts[c - 1] = dragged;
+        if (opt.indices_only) return;
         if (st.mode != kModeWide) { finish_narrow_step(st, w); return; }
 
         // WIDE: the cut is [dragged..., new...]; the new x new block becomes a step of its own

@@ -81,6 +81,8 @@ struct Plan {
 struct PlanOptions {
     int32_t full_max_floats = 8192;    // rows longer than this use the pipelined SPLIT kernel even when two rows would fit (tuned on genea140 / cfg3)
     int32_t lds_cap_floats = 36864;   // floats of LDS a workgroup may use for staged source rows (9 * 1024 float4; 160 KB minus the work-queue slots)
+    bool indices_only = false;        // cuts and per-member sources / rank words only (every step marked FULL, no pk words, no
+                                      // work order, the last cut in proband order): what the column-panel multi-GPU path needs
 };
 
 // Returns 0 or a GENPHI_ERR_* code (see include/genphi.h); message in err.

@@ -6,7 +6,7 @@
 # in libgenphi.so (include/genphi.h) on the GPU instead of under Threads.@threads.
 # Everything else (gen.genealogy, gen.pro, the Pedigree container) stays GenLib.jl's own.
 #
-# NOT exercised in the build container (no Julia there); see INTEGRATION.md.
+# NOT exercised in the build container (no Julia there, nor on the GPU boxes); see INTEGRATION.md.
 module GenLibAMD
 
 import GenLib
@@ -19,8 +19,9 @@ struct GenphiOpts              # mirrors genphi_opts (include/genphi.h)
     row_begin::Int64
     row_end::Int64
     timing::Int32
-    reserved::Int32
+    reserved::Int32            # flags: 1 = no hipGraph replay, 2 = Float64 level matrices (GENPHI_FLAG_STORAGE_F64)
 end
+const FLAG_STORAGE_F64 = Int32(2)
 
 last_error() = unsafe_string(ccall((:genphi_last_error, libgenphi), Cstring, ()))
 
@@ -31,13 +32,6 @@ function check(rc::Cint)
     (rc == 1 || rc == 2) ? throw(KeyError(msg)) : error("libgenphi: $msg (code $rc)")
 end
 
-"""
-    phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
-        verbose::Bool = false, compute::Bool = true, device::Integer = -1)
-
-Square `Matrix{Float32}` of pairwise kinship coefficients between probands, bit-identical to
-`GenLib.phi`, computed on an MI355X.
-"""
 # flatten in rank order (the traversal of GenLib.genout, src/output.jl:24-29, kept at 64 bit)
 function flatten(pedigree::GenLib.Pedigree)
     n = length(pedigree)
@@ -52,6 +46,13 @@ function flatten(pedigree::GenLib.Pedigree)
     ind, father, mother, sex
 end
 
+"""
+    phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
+        verbose::Bool = false, compute::Bool = true, device::Integer = -1)
+
+Square `Matrix{Float32}` of pairwise kinship coefficients between probands, bit-identical to
+`GenLib.phi`, computed on an MI355X.
+"""
 function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
              verbose::Bool = false, compute::Bool = true, device::Integer = -1)
     ind, father, mother, _ = flatten(pedigree)
@@ -92,11 +93,30 @@ function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(ped
 end
 
 """
+    phi(individualᵢ::GenLib.Individual, individualⱼ::GenLib.Individual, pedigree::GenLib.Pedigree; device = -1)
+
+Float64 kinship of a pair, as `GenLib.phi(individualᵢ, individualⱼ)` (src/compute.jl:66-95), from one
+Float64 level sweep on the GPU instead of the un-memoised recursion.  (The reference's method needs no
+pedigree argument because its `Individual`s carry pointers to their parents; the flat arrays the
+library takes are built from the pedigree.)  Bit-identical while kinships are exactly representable in
+Float64 (pedigrees less than ~26 generations deep), within 1e-15 relative beyond.
+"""
+function phi(individualᵢ::GenLib.Individual, individualⱼ::GenLib.Individual, pedigree::GenLib.Pedigree;
+             device::Integer = -1)
+    ind, father, mother, _ = flatten(pedigree)
+    a = Int64[individualᵢ.ID]; b = Int64[individualⱼ.ID]; out = Vector{Float64}(undef, 1)
+    GC.@preserve ind father mother a b out check(ccall((:genphi_phi_pairs, libgenphi), Cint,
+        (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32),
+        length(ind), ind, father, mother, 1, a, b, out, Int32(device)))
+    out[1]
+end
+
+"""
     f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
 
 Coefficients of inbreeding (`Vector{Float32}`), as `GenLib.f` (src/compute.jl:500-511), from ONE
-level sweep over the parents on the GPU plus point lookups, instead of one un-memoised pairwise
-recursion per individual.  Agrees with `GenLib.f` to the Float32-per-level rounding (~3e-8).
+Float64 level sweep over the parents on the GPU plus point lookups, instead of one un-memoised
+pairwise recursion per individual; rounded to Float32 once, like the reference.
 """
 function f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
     coefficients = zeros(Float32, length(IDs))
@@ -114,7 +134,7 @@ function f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
                     length(ind), ind, father, mother, length(parents), parents, plan))
     end
     try
-        opts = Ref(GenphiOpts(Int32(device), 0, 0, 0, 0, 0))
+        opts = Ref(GenphiOpts(Int32(device), 0, 0, 0, 0, FLAG_STORAGE_F64))
         check(ccall((:genphi_compute_device, libgenphi), Cint, (Ptr{Cvoid}, Ptr{GenphiOpts}, Ptr{Cvoid}),
                     plan[], opts, C_NULL))
         values64 = Vector{Float64}(undef, length(known))
@@ -125,6 +145,53 @@ function f(pedigree::GenLib.Pedigree, IDs::Vector{Int}; device::Integer = -1)
         ccall((:genphi_plan_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), plan[])
     end
     coefficients
+end
+
+"""
+    KinshipMatrix, sparse_phi(pedigree, probandIDs = GenLib.pro(pedigree); device = -1)
+
+As `GenLib.sparse_phi` / `GenLib.KinshipMatrix` (src/compute.jl:321-447, :31-46): `ϕ[ID₁, ID₂]`,
+`show`, `phiMean(ϕ)`; computed on the GPU one depth at a time (csrc/sparse_phi.hip).
+"""
+mutable struct KinshipMatrix
+    handle::Ptr{Cvoid}
+    function KinshipMatrix(h::Ptr{Cvoid})
+        ϕ = new(h)
+        finalizer(x -> ccall((:genphi_sparse_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), x.handle), ϕ)
+    end
+end
+
+function sparse_phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree); device::Integer = -1)
+    ind, father, mother, _ = flatten(pedigree)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ind father mother probandIDs check(ccall((:genphi_sparse_phi, libgenphi), Cint,
+        (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
+        length(ind), ind, father, mother, length(probandIDs), probandIDs, Int32(device), h))
+    KinshipMatrix(h[])
+end
+
+function info(ϕ::KinshipMatrix)
+    n = Ref{Int64}(0); nz = Ref{Int64}(0); total = Ref{Float64}(0); diagonal = Ref{Float64}(0)
+    check(ccall((:genphi_sparse_info, libgenphi), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+                ϕ.handle, n, nz, total, diagonal))
+    n[], nz[], total[], diagonal[]
+end
+
+function Base.getindex(ϕ::KinshipMatrix, ID₁::Int, ID₂::Int)
+    a = Int64[ID₁]; b = Int64[ID₂]; out = Vector{Float64}(undef, 1)
+    GC.@preserve a b out check(ccall((:genphi_sparse_get, libgenphi), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), ϕ.handle, 1, a, b, out))
+    out[1]
+end
+
+function Base.show(io::IO, ::MIME"text/plain", ϕ::KinshipMatrix)
+    n, nz, _, _ = info(ϕ)
+    print(io, "$(n)×$(n) KinshipMatrix with $nz stored entries.")
+end
+
+function phiMean(ϕ::KinshipMatrix)::Float32
+    n, _, total, diagonal = info(ϕ)
+    (total - diagonal) / (n * (n - 1) / 2)
 end
 
 """

@@ -211,6 +211,31 @@ int genphi_sparse_get(const genphi_sparse *h, int64_t n, const int64_t *id1, con
 int64_t genphi_sparse_entries(const genphi_sparse *h, int64_t cap, int64_t *row_rank, int64_t *col_rank, float *val);
 void genphi_sparse_destroy(genphi_sparse *h);
 
+/* ---- storage-sharded gen.phi: column panels + an exchange step (csrc/panel_phi.hip) --------------------
+ * For pedigrees whose level matrices do not fit one GPU (the reference keeps two dense level matrices
+ * alive, src/compute.jl:291,301).  Rank r of `world` stores the column panel of the members it owns (all
+ * rows x its columns: 1/world of every level matrix) and, before every level step, receives the parent
+ * columns of its new members that other ranks own.  This library packs / consumes DEVICE buffers; the
+ * all-to-all itself is issued by the host (torch.distributed over RCCL/xGMI: genlib.jl_amd/distributed.py).
+ *   create            plan + ownership + exchange lists (host only; identical arguments on every rank)
+ *   begin             upload, Psi_1 = 1/2 I on the local columns
+ *   exchange_counts   columns to send to / receive from every rank before step `step`, floats per column
+ *   pack / compute    fill the send buffer; unpack the received columns and run the level step
+ *   result_to_host    this rank's row block [row_begin, row_begin + n_rows) of Phi (proband order)      */
+typedef struct genphi_panel genphi_panel;
+int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                        int64_t n_pro, const int64_t *pro_ids, int32_t rank, int32_t world, genphi_panel **out);
+int64_t genphi_panel_n_steps(const genphi_panel *p);
+int64_t genphi_panel_n_probands(const genphi_panel *p);
+int genphi_panel_result_rows(const genphi_panel *p, int64_t *row_begin, int64_t *n_rows);
+int genphi_panel_exchange_counts(const genphi_panel *p, int32_t step, int64_t *send_cols, int64_t *recv_cols, int64_t *col_floats);
+double genphi_panel_device_bytes(const genphi_panel *p);
+int genphi_panel_begin(genphi_panel *p, int32_t device);
+int genphi_panel_pack(genphi_panel *p, int32_t step, float *d_send);
+int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv);
+int genphi_panel_result_to_host(genphi_panel *p, float *out);
+void genphi_panel_destroy(genphi_panel *p);
+
 /* Frees host and device memory of the plan (NULL is allowed). */
 void genphi_plan_destroy(genphi_plan *plan);
 

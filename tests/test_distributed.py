@@ -47,3 +47,68 @@ def test_two_ranks_share_one_gpu():
                     "--single-device", "--no-cpu-baseline"], 29534)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["unit"] == "proband-pairs/s" and d["roofline"]["bound"] == "hbm"
+
+
+def test_panel_exchange_lists_are_consistent():
+    """Storage-sharded gen.phi (column panels, include/genphi.h genphi_panel_*): host-side check, no
+    GPU -- what rank a sends to rank b before a step is what b expects from a, the result row blocks
+    tile [0, N), and a single rank exchanges nothing."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth, _capi
+    ind, fa, mo, sex, pro = synth.random_mating(4000, 301, 9, skip_permille=100, seed=2)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    for world in (1, 2, 3, 8):
+        plans = [_capi.PanelPlan(ped.ind, ped.father, ped.mother, pro, r, world) for r in range(world)]
+        blocks = [p.result_rows() for p in plans]
+        assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == len(pro)
+        assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+        total = 0
+        for step in range(plans[0].n_steps):
+            cnt = [p.exchange_counts(step) for p in plans]
+            for a in range(world):
+                assert cnt[a][0][a] == 0 and cnt[a][1][a] == 0                  # nothing to oneself
+                for b in range(world):
+                    assert cnt[a][0][b] == cnt[b][1][a]                          # a -> b is what b expects from a
+                assert cnt[a][2] == cnt[0][2]
+                total += int(cnt[a][0].sum())
+        assert (total == 0) == (world == 1)
+        if world > 1:                                  # a rank holds about 1 / world of what a single rank holds
+            one = _capi.PanelPlan(ped.ind, ped.father, ped.mother, pro, 0, 1)
+            assert all(0 < p.device_bytes < 0.9 * one.device_bytes for p in plans)
+            one.close()
+        for p in plans:
+            p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [1, 2, 3])
+def test_panel_mode_matches_the_oracle(nproc):
+    """The exchange path end to end: `nproc` ranks (gloo; all on cuda:0) each hold a column panel of
+    every level, exchange parent columns before every step, and their row blocks reassemble to the
+    oracle's matrix bit for bit (geneaJi, overlapping generations, one-parent members, ancestors among
+    the probands)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "panel_worker.py")
+    if nproc == 1:
+        cmd = [sys.executable, worker]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29540 + nproc), worker]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    d = json.loads(lines[-1])
+    assert d["ok"] and d["world"] == nproc
+    assert (d["exchange_bytes_sent_rank0"] > 0) == (nproc > 1)
+
+
+@pytest.mark.gpu
+def test_bench_exchange_mode_two_ranks_one_gpu():
+    """bench.py --exchange: the storage-sharded path (column panels + an all-to-all per level step)
+    through the same launcher contract, two gloo ranks sharing cuda:0."""
+    d = _launch(2, ["--workload", "cfg5", "--steps", "1", "--warmup", "1", "--backend", "gloo", "--single-device",
+                    "--no-cpu-baseline", "--exchange"], 29537)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["why_exchange"] == "forced"
+    assert d["config"]["exchange_bytes_sent_per_rank_max"] > 0
