@@ -1,58 +1,103 @@
-"""One-off extended stress (not collected by pytest): random pedigrees x kernel modes x shards x
-proband subsets against the oracle.  usage (GPU box): python tests/stress_random.py [seconds] [seed]"""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import genlib_jl_amd as gen
-from oracle import oracle
-from test_gpu_parity import _random_pedigree
+"""Random stress of the GPU path against the oracle (not part of the pytest run; run on a GPU box:
+    python tests/stress_random.py [seconds] [seed]
+Random pedigrees x kernel families (LDS budget forces FULL / SPLIT / WIDE) x certificate thresholds
+(mixed fast / grouping-exact SPLIT levels) x workgroup variants x proband subsets x row shards x the
+Float64 sweep x sparse_phi, every result compared with the oracle bit for bit.  Prints one line per
+failure with everything needed to reproduce it, and a summary."""
+import os
+import sys
+import time
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0, cases, fails = time.time(), 0, 0
-while time.time() - t0 < budget:
-    n = int(rng.choice([30, 120, 400, 900, 1500, 1500, 4000]))
-    pf, p1, ps = rng.choice([0.01, 0.05, 0.3]), rng.choice([0.0, 0.1, 0.3]), rng.choice([0.0, 0.05])
-    back = int(rng.choice([5, 50, 400, n]))
-    ind, fa, mo, sex = _random_pedigree(rng, n, pf, p1, ps, back)
-    oped = oracle.Pedigree(ind, fa, mo)
-    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
-    cap = rng.choice([0, 0, 4096, 900, 150])
-    os.environ.pop("GENPHI_LDS_CAP_FLOATS", None)
-    if cap:
-        os.environ["GENPHI_LDS_CAP_FLOATS"] = str(cap)
-    os.environ.pop("GENPHI_FULL_MAX_FLOATS", None)
-    if rng.random() < 0.3:
-        os.environ["GENPHI_FULL_MAX_FLOATS"] = "64"          # SPLIT kernel on small rows
-    pro = oped.pro() if rng.random() < 0.5 else rng.choice(ind, size=int(rng.integers(1, min(n, 300) + 1)), replace=True)
-    want = oped.phi(pro)
-    pl = gen.plan(ped, pro)
-    N = pl.n_probands
-    got = pl.compute()
-    ok = np.array_equal(got, want)
-    if N >= 3:
-        a, b = sorted(int(x) for x in rng.choice(np.arange(1, N), size=2, replace=False))
-        parts = np.concatenate([pl.compute(rows=r) for r in ((0, a), (a, b), (b, N))], axis=0)
-        ok = ok and np.array_equal(parts, want)
-    modes = sorted(set(pl.step_modes()))
-    # the same plan again (hipGraph replay from the second untimed sweep on), the naive kernel,
-    # point lookups and the on-device sums
-    if rng.random() < 0.3:
-        ok = ok and np.array_equal(pl.compute(), want) and np.array_equal(pl.compute(), want)
-        ok = ok and np.array_equal(pl.compute(kernel=1), want)
-        if N:
-            r_, c_ = rng.integers(0, N, 5), rng.integers(0, N, 5)
-            pl.compute_device()
-            ok = ok and np.array_equal(pl.result_entries(r_, c_), want[r_, c_].astype(np.float64))
-            a_, d_, _ = pl.result_sums()
-            w64 = want.astype(np.float64)
-            ok = ok and abs(a_ - w64.sum()) <= 1e-9 * max(1.0, w64.sum()) and abs(d_ - np.trace(w64)) <= 1e-9 * max(1.0, np.trace(w64))
-    pl.close()
-    cases += 1
-    if cases % 25 == 0:
-        print(f"... {cases} cases, {fails} mismatches, {time.time() - t0:.0f} s", flush=True)
-    if not ok:
-        fails += 1
-        print("MISMATCH", dict(n=n, pf=pf, p1=p1, ps=ps, back=back, cap=int(cap), N=N, modes=modes), flush=True)
-print(f"{cases} cases, {fails} mismatches in {time.time() - t0:.0f} s")
-sys.exit(1 if fails else 0)
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
+         "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP"]
+
+
+def main():
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    from oracle import oracle as O
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rng = np.random.default_rng(seed0)
+    t0, n_cases, n_fail = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        case = int(rng.integers(1 << 30))
+        r = np.random.default_rng(case)
+        n_gen = int(r.integers(3, 16))
+        n_pro = int(r.integers(5, 400))
+        n_ind = n_pro + (n_gen - 1) * int(r.integers(20, 500))
+        skip = int(r.choice([0, 0, 30, 150, 400]))
+        ind, fa, mo, sex, pro = synth.random_mating(n_ind, n_pro, n_gen, seed=case, skip_permille=skip)
+        if r.random() < 0.3:
+            mo = mo.copy(); mo[:: int(r.integers(7, 40))] = 0                   # one-parent members
+        if r.random() < 0.4:                                                  # probands: a subset, some ancestors, duplicates
+            extra = ind[r.integers(0, len(ind), size=int(r.integers(1, 20)))]
+            pro = np.concatenate([r.permutation(pro)[: max(2, n_pro // 2)], extra, pro[:2]])
+        env = {}
+        if r.random() < 0.7:
+            env["GENPHI_LDS_CAP_FLOATS"] = str(int(r.choice([64, 256, 700, 1500, 4096])))
+        if r.random() < 0.3:
+            env["GENPHI_FULL_MAX_FLOATS"] = "0"
+        if r.random() < 0.5:
+            env["GENPHI_CERT_MIN_EXP"] = str(int(r.integers(-27, 0)))
+        if r.random() < 0.3:
+            env["GENPHI_FAST_NT"] = str(int(r.choice([512, 1024])))
+        if r.random() < 0.15:
+            env["GENPHI_NO_FAST"] = "1"
+        if r.random() < 0.3:
+            env["GENPHI_MAX_CPT"] = str(int(r.choice([4, 8, 16])))
+        if r.random() < 0.2:
+            env["GENPHI_NO_SMALL"] = "1"
+        if r.random() < 0.2:
+            env["GENPHI_MAX_GROUP"] = str(int(r.choice([1, 3, 8])))
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        oped = O.Pedigree(ind, fa, mo)
+        want = oped.phi(pro)
+        n = len(want)
+        what = []
+        try:
+            pl = gen.plan(ped, pro)
+            if not np.array_equal(pl.compute(), want):
+                what.append("full")
+            if n > 2:
+                a = int(r.integers(0, n - 1)); b = int(r.integers(a + 1, n + 1))
+                if not np.array_equal(pl.compute(rows=(a, b)), want[a:b]):
+                    what.append(f"shard({a},{b})")
+                if not np.array_equal(pl.compute(), want):
+                    what.append("full-after-shard")
+            if r.random() < 0.2 and not np.array_equal(pl.compute(kernel=1), want):
+                what.append("naive")
+            pl.close()
+            if r.random() < 0.25:
+                ids = r.choice(ind, size=min(30, len(ind)), replace=False)
+                if not np.array_equal(gen.f(ped, ids), oped.f(ids)):
+                    what.append("f")
+            if r.random() < 0.25 and n_ind < 3000:
+                sub = list(dict.fromkeys(int(x) for x in pro))[:40]
+                K = gen.sparse_phi(ped, sub)
+                Ko = O.SparsePhi(oped, sub)
+                got = K.get(np.repeat(sub, len(sub)), np.tile(sub, len(sub))).reshape(len(sub), len(sub)).astype(np.float32)
+                if not np.array_equal(got, Ko.matrix()) or repr(K) != Ko.show():
+                    what.append("sparse")
+        except Exception as e:          # noqa: BLE001
+            what.append(f"exception {type(e).__name__}: {e}")
+        n_cases += 1
+        if what:
+            n_fail += 1
+            print(f"FAIL case={case} gens={n_gen} n_ind={n_ind} n_pro={n_pro} skip={skip} env={env} -> {what}", flush=True)
+        if n_cases % 20 == 0:
+            print(f"... {n_cases} cases, {n_fail} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"stress: {n_cases} cases, {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
+    return 1 if n_fail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

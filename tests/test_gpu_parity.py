@@ -709,3 +709,26 @@ def test_sparse_phi_kinship_matrix(gen, oracle):
     g = oracle.read_tsv(gen.genea140)
     ped = gen.genealogy(gen.genea140)
     _sparse_check(gen, oracle, *g, pro=gen.pro(ped)[:25])
+
+
+def test_cfg4o_downscaled_twin(gen, oracle, monkeypatch):
+    """The overlapping-generations workload of bench.py (cfg4o: cfg4's generator with 0.5 % of the parents
+    drawn from generation g-2) at 1/50 of its size, with the LDS budget scaled so that the planner picks
+    the same kernel families level by level as at full size (SPLIT, 23 x WIDE, 5 x SPLIT): bit-equal to
+    the oracle, with the default and with the grouping-exact SPLIT kernels."""
+    from genlib_jl_amd import synth
+    monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", "750")
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")
+    ind, fa, mo, sex, pro = synth.random_mating(20_000, 2_000, 30, skip_permille=5)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    pl = gen.plan(ped, pro)
+    assert pl.step_modes() == [1] + [2] * 23 + [1] * 5                   # cfg4o's own sequence (profiles/r02_bench_cfg4o.json)
+    sizes, both = pl.levels()
+    assert max(sizes) > 2300 and max(b / s for b, s in zip(both, sizes[1:])) > 0.75      # most of a cut is dragged along
+    _assert_equal(pl.compute(), want)
+    monkeypatch.setenv("GENPHI_NO_FAST", "1")
+    _assert_equal(pl.compute(), want)
+    pl.close()
+    for k in ("GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_FAST"):
+        monkeypatch.delenv(k, raising=False)
