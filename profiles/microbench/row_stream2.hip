@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int RD, int WR, int K, bool NTS>   // K float4 per thread per row
+template <int NT, int RD, int WR, int K, bool NTS, bool NTL = false>   // K float4 per thread per row; NTS / NTL: non-temporal stores / loads
 __global__ void __launch_bounds__(NT) stream(const float *__restrict__ in, float *__restrict__ out, int n_rows, int stages)
 {
     constexpr int ROW = NT * K * 4;
@@ -18,7 +18,11 @@ __global__ void __launch_bounds__(NT) stream(const float *__restrict__ in, float
             r = (r + 256u * 37u) % n_rows;
             const float *src = in + (size_t)r * ROW;
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const f4 v = *reinterpret_cast<const f4 *>(src + (tl + k * NT) * 4); acc += v; }
+            for (int k = 0; k < K; ++k) {
+                const f4 *q = reinterpret_cast<const f4 *>(src + (tl + k * NT) * 4);
+                const f4 v = NTL ? __builtin_nontemporal_load(q) : *q;
+                acc += v;
+            }
         }
         for (int a = 0; a < WR; ++a) {
             r = (r + 256u * 37u) % n_rows;
@@ -33,7 +37,7 @@ __global__ void __launch_bounds__(NT) stream(const float *__restrict__ in, float
     if (acc[0] == 12345.f) out[0] = acc[1];
 }
 
-template <int NT, int RD, int WR, int K, bool NTS>
+template <int NT, int RD, int WR, int K, bool NTS, bool NTL = false>
 static void run(const char *name, const float *in, float *out, size_t bytes_buf, int stages, int grid)
 {
     constexpr int ROW = NT * K * 4;
@@ -42,7 +46,7 @@ static void run(const char *name, const float *in, float *out, size_t bytes_buf,
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(a);
-        hipLaunchKernelGGL((stream<NT, RD, WR, K, NTS>), dim3(grid), dim3(NT), 0, 0, in, out, n_rows, stages);
+        hipLaunchKernelGGL((stream<NT, RD, WR, K, NTS, NTL>), dim3(grid), dim3(NT), 0, 0, in, out, n_rows, stages);
         (void)hipEventRecord(b); (void)hipEventSynchronize(b);
         float ms; (void)hipEventElapsedTime(&ms, a, b);
         if (rep > 0 && ms < best) best = ms;
@@ -64,6 +68,9 @@ int main()
     run<1024, 3, 2, 6, true >("1024 thr, 96 KB rows: 3 reads : 2 writes, nt stores", in, out, buf, 48, 256);
     run<1024, 1, 3, 8, false>("1024 thr, 128 KB rows: 1 read : 3 writes (final level)", in, out, buf, 48, 256);
     run<1024, 1, 3, 8, true >("1024 thr, 128 KB rows: 1 read : 3 writes, nt stores", in, out, buf, 48, 256);
+    run<1024, 1, 0, 6, false, true>("1024 thr, 96 KB rows: reads only, nt loads", in, out, buf, 96, 256);
+    run<1024, 3, 2, 6, true, true>("1024 thr, 96 KB rows: 3 reads : 2 writes, nt stores + nt loads", in, out, buf, 48, 256);
+    run<1024, 1, 3, 8, true, true>("1024 thr, 128 KB rows: 1 read : 3 writes, nt stores + nt loads", in, out, buf, 48, 256);
     run<512, 3, 2, 12, false>("512 thr x 256 WG, 96 KB rows: 3 reads : 2 writes", in, out, buf, 48, 256);
     run<512, 3, 2, 12, false>("512 thr x 512 WG, 96 KB rows: 3 reads : 2 writes", in, out, buf, 24, 512);
     run<512, 1, 3, 16, false>("512 thr x 256 WG, 128 KB rows: 1 read : 3 writes", in, out, buf, 48, 256);
