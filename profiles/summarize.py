@@ -38,26 +38,41 @@ def agg(path):
 
 
 F, W = agg(one("pmc_fetch/*/*counter_collection.csv")), agg(one("pmc_write/*/*counter_collection.csv"))
-rows, tot = [], 0.0
+KERNELS = ("level_", "levels_small", "rows_compact", "transpose_block", "copy_block", "pad_zero", "colperm", "group_split")
+rows, tot, sweeps, steps = [], 0.0, 0, 0
 for k in F:
-    if "level_" not in F[k]["name"] or k not in W:
+    name = F[k]["name"]
+    if not any(t in name for t in KERNELS) or k not in W:
         continue
-    if F[k]["ms"] < 0.02 and "level_split_kernel" in F[k]["name"]:
+    short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+    if "level_identity_kernel" in name:
+        sweeps += 1                                        # one per gen.phi sweep (level step 0)
+    if F[k]["ms"] < 0.02 and "level_split_kernel" in name:
         continue            # the grouping-exact SPLIT kernel of a level whose groups are all certified: it finds an empty list and ends at once
     rd = F[k].get("FETCH_SIZE", 0.0) * 1024 * 2            # KiB -> B, gfx950 wide-read correction
     wr = W[k].get("WRITE_SIZE", 0.0) * 1024
     hit, miss = W[k].get("TCC_HIT_sum", 0.0), W[k].get("TCC_MISS_sum", 0.0)
-    short = F[k]["name"].split("(anonymous namespace)::")[1].split("(")[0]
     rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1)))
     tot += rd + wr
 with open(os.path.join(dst, f"{tag}_{wl}_levels.csv"), "w") as fh:
     fh.write("dispatch,kernel,ms_under_pmc,hbm_read_bytes,hbm_write_bytes,l2_hit_pct\n")
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
-n = max(len(rows), 1)
-json.dump({"workload": wl, "tag": tag, "level_kernel_launches_profiled": len(rows),
-           "hbm_bytes_per_launch": tot / n,
+# level steps per sweep: from the bench line of the kernel-trace run
+n_steps = None
+try:
+    for line in open(os.path.join(src, "kt.log")):
+        if line.startswith("{"):
+            n_steps = json.loads(line)["roofline"]["launches_per_step"]
+except Exception:
+    pass
+sweeps = max(sweeps, 1)
+per_step = tot / sweeps / n_steps if n_steps else None
+json.dump({"workload": wl, "tag": tag, "sweeps_profiled": sweeps, "level_steps_per_sweep": n_steps,
+           "hbm_bytes_per_sweep": tot / sweeps,
+           "hbm_bytes_per_launch": per_step,
            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE in separate passes, "
-                     "KiB -> bytes, averaged over the level-kernel launches of 2 bench steps"},
+                     "KiB -> bytes, summed over every kernel of the profiled gen.phi sweeps; per launch = per level step "
+                     "(a WIDE level step is several kernels)"},
           open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
-print(f"{len(rows)} launches, {tot / n / 1e9:.3f} GB per launch")
+print(f"{len(rows)} dispatches, {sweeps} sweeps, {tot / sweeps / 1e9:.2f} GB per sweep" + (f", {per_step / 1e9:.3f} GB per level step" if per_step else ""))

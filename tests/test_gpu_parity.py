@@ -726,8 +726,13 @@ def test_cfg4o_downscaled_twin(gen, oracle, monkeypatch):
     assert pl.step_modes() == [1] + [2] * 23 + [1] * 5                   # cfg4o's own sequence (profiles/r02_bench_cfg4o.json)
     sizes, both = pl.levels()
     assert max(sizes) > 2300 and max(b / s for b, s in zip(both, sizes[1:])) > 0.75      # most of a cut is dragged along
+    for _ in range(4):                                                   # eager, hipGraph capture, two replays (29 level steps)
+        _assert_equal(pl.compute(), want)
+    _assert_equal(pl.compute(rows=(100, 900)), want[100:900])            # a WIDE plan with a row shard, then the full sweep again
     _assert_equal(pl.compute(), want)
+    pl.close()
     monkeypatch.setenv("GENPHI_NO_FAST", "1")
+    pl = gen.plan(ped, pro)
     _assert_equal(pl.compute(), want)
     pl.close()
     for k in ("GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_FAST"):
