@@ -24,7 +24,7 @@
 //       passes: rows_compact_kernel (dragged x dragged = a stream compaction of the previous
 //       matrix; new x dragged = the compacted half sum of two rows; the parent x parent matrix),
 //       transpose_block_kernel (dragged x new), a FULL / SPLIT sub-step on the compacted parent
-//       matrix (new x new), copy_block_kernel, pad_zero_kernel.
+//       matrix that writes the new x new block in place, pad_zero_kernel.
 //   levels_small_kernel a RUN of consecutive steps with cuts <= 128 members in one persistent
 //       launch: both level matrices live in LDS, one barrier per level (deep small pedigrees
 //       are launch-bound otherwise).
@@ -102,6 +102,7 @@ struct LevelArgs {
     float *out;              // this level's matrix (or the shard buffer of the last level)
     long long ld_prev, ld;
     int n_prev, n;
+    int width;               // columns a row kernel writes: [0, n) and the zero padding [n, width); = ld except in the new x new sub-step of a WIDE level
     const int *srcA, *srcB, *ord;   // per member of this cut (storage order)
     const unsigned *pk;      // srcA | srcB << 16 (FULL / SPLIT modes: n_prev < 65536)
     const int *rows;         // work list: storage row ids (n_rows entries)
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
     }
     if (p.cert_out && ck < p.cert_thresh) p.cert_out[r.i] = 1;      // exactness certificate of the row (see cert_key)
     // zero columns [n, ld): the "none" column of this level and its pitch padding
-    for (long long j = p.n + tid; j < p.ld; j += nt) r.orowp[j] = 0.f;
+    for (long long j = p.n + tid; j < p.width; j += nt) r.orowp[j] = 0.f;
 }
 
 // ---- SPLIT: one whole source row in LDS at a time (cuts of ~20k..40k members) ----------------
@@ -391,7 +392,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
     // columns [n, ld) (the "none" column and the pitch padding) are written as part of the
     // last chunk: their padded index words point at the zero column, so they come out as 0
-    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
+    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
 
 #pragma unroll
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
@@ -584,7 +585,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
+            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
         }
     }
 #if GENPHI_WG_TIMES
@@ -655,7 +656,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
     bool stage_is_a = true;
     bool have_next = nxt_l < n_items;
     unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
+    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
 
 #pragma unroll
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
@@ -779,7 +780,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.ld);
+            ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
         }
     }
 }
@@ -900,19 +901,6 @@ transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows
             if (cert_out && cert_key(v) < cert_thresh) cert_out[c] = 1;
         }
     }
-}
-
-// dst[dst_row0 + r][dst_col0 + c] = src[r][c] for r < rows, c < cols (the new x new block computed
-// by the sub-step into its own buffer)
-__global__ void __launch_bounds__(256)
-copy_block_kernel(const float *__restrict__ src, long long ld_src, int rows, int cols, float *__restrict__ dst, long long ld_dst,
-                  int dst_row0, int dst_col0)
-{
-    const int r = blockIdx.x;                          // rows on x: grid.y is limited to 65535
-    if (r >= rows) return;
-    const float *s_ = src + (long long)r * ld_src;
-    float *d_ = dst + (long long)(dst_row0 + r) * ld_dst + dst_col0;
-    for (int c = blockIdx.y * 1024 + threadIdx.x; c < min(cols, (int)(blockIdx.y + 1) * 1024); c += 256) d_[c] = s_[c];
 }
 
 // zero padding of a level matrix: columns [n, ld) of rows 0..n-1 and the whole "none" row n
@@ -1332,7 +1320,7 @@ struct genphi_plan {
     std::vector<DeviceStep> dsteps;
     std::vector<const LevelStep *> nn_steps;     // new x new sub-steps of the WIDE steps (owned by the plan's steps)
     std::vector<DeviceStep> nn_dsteps;
-    float *psi_p = nullptr, *nn_out = nullptr;   // WIDE: compacted parent matrix, the sub-step's result
+    float *psi_p = nullptr;                      // WIDE: compacted parent matrix Psi[parents][parents]
     int *d_cert_p = nullptr;                     // certificates of the rows of psi_p
     size_t cert_p_words = 0;
     int *d_final_perm = nullptr;
@@ -1408,7 +1396,7 @@ static void free_device(genphi_plan *p)
     p->shard_groups = DeviceGroups(); p->shard_blob_bytes = 0; p->cert_off.clear(); p->cert_words = 0;
     release(p->d_queues); release(p->d_small); release(p->sh_blob); release(p->scratch);
     release(p->buf[0]); release(p->buf[1]); release(p->result); release(p->final_tmp);
-    release(p->psi_p); release(p->nn_out); release(p->d_cert_p);
+    release(p->psi_p); release(p->d_cert_p);
     release(p->buf64[0]); release(p->buf64[1]); release(p->result64); release(p->d_perm_rows);
     p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
     p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
@@ -1540,7 +1528,7 @@ static int upload_plan(genphi_plan *p, int device)
         const LevelStep &s = step_at(k);
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
         if (s.mode == genphi::kModeSplit) {
-            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.n), step_groups[k]);
+            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k]);
             total += groups_bytes(step_groups[k]);
         }
         if (s.mode == genphi::kModeWide)
@@ -1631,19 +1619,16 @@ static int upload_plan(genphi_plan *p, int device)
         }
         p->buf_floats[b] = need[b];
     }
-    // WIDE steps: the compacted parent matrix, the sub-step's result, the parent rows' certificates
+    // WIDE steps: the compacted parent matrix and its rows' certificates
     {
-        size_t need_p = 0, need_o = 0, need_c = 0;
+        size_t need_p = 0, need_c = 0;
         for (const LevelStep *nn : p->nn_steps) {
             need_p = std::max(need_p, static_cast<size_t>((nn->n_prev + 1) * nn->ld_prev) + kTailPadFloats);
-            need_o = std::max(need_o, static_cast<size_t>((nn->n + 1) * nn->ld) + kTailPadFloats);
             need_c = std::max(need_c, static_cast<size_t>(nn->n_prev) + 1);
         }
         if (need_p) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->psi_p, 0, need_p * sizeof(float), p->stream));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->nn_out), need_o * sizeof(float)));
-            HIP_TRY(hipMemsetAsync(p->nn_out, 0, need_o * sizeof(float), p->stream));
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cert_p), need_c * sizeof(int)));
             p->cert_p_words = need_c;
         }
@@ -1809,6 +1794,7 @@ struct LevelCtx {
     const int *cert_prev;      // certificates of the source rows / of the rows written (nullptr: last level)
     int *cert_out;
     bool identity;             // the source matrix is Psi_1 = 1/2 I, never materialised
+    bool no_none_row;          // sub-step of a WIDE level: the "none" row belongs to the enclosing level
     bool dbg;                  // GENPHI_WG_TIMES builds: record this launch
 };
 
@@ -1819,6 +1805,7 @@ static LevelCtx main_ctx(genphi_plan *p, int step)
     c.cert_prev = p->d_cert + p->cert_off[step];
     c.cert_out = p->d_cert + p->cert_off[step + 1];      // (the last level's have no reader: harmless)
     c.identity = identity_source(step);
+    c.no_none_row = false;
     const char *e = std::getenv("GENPHI_DBG_STEP");                            // default: the last step
     c.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step;
     return c;
@@ -1831,13 +1818,13 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
     const DeviceStep &d = *cx.d;
     const int step = cx.slot;
     LevelArgs a;
-    a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld;
+    a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.width = static_cast<int>(s.width);
     a.n_prev = static_cast<int>(s.n_prev); a.n = static_cast<int>(s.n);
     a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.pk = d.pk;
     a.rows = rows; a.out_rows = out_rows; a.n_rows = n_rows;
     a.lds_row = 0; a.chunk_cols = 0;
     a.dbg = cx.dbg ? 1 : 0;
-    a.zero_row = (out_rows == nullptr && kernel != 1) ? 1 : 0;
+    a.zero_row = (out_rows == nullptr && kernel != 1 && !cx.no_none_row) ? 1 : 0;
     a.cert_prev = cx.cert_prev;
     a.cert_out = out_rows == nullptr ? cx.cert_out : nullptr;
     a.glist = nullptr; a.gcnt = nullptr; a.chunk_magic = 0;
@@ -1845,7 +1832,8 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
     if (n_rows <= 0) {
         // nothing to compute (a row shard whose ancestors do not reach this level), but the next level
         // still reads this level's all-zero "none" row for its parentless members
-        if (out_rows == nullptr) HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
+        if (out_rows == nullptr && !cx.no_none_row)
+            HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
         return GENPHI_OK;
     }
     const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
@@ -1882,7 +1870,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
         // LDS must also absorb the unconditional over-write past the row's end
         const size_t lds_stage_s = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt_s * 16);
         const size_t lds = lds_stage_s + 32 + (GENPHI_WG_TIMES ? 128 : 0);
-        const int per_thread = static_cast<int>((s.ld + nt_s - 1) / nt_s);     // the padding columns [n, ld) are written too
+        const int per_thread = static_cast<int>((s.width + nt_s - 1) / nt_s);     // the padding columns [n, ld) are written too
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
         int max_cpt;
         if (s.pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
@@ -1901,13 +1889,13 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
                 if (force_nt && nt != force_nt) continue;
                 int stg = (per_row4 + nt - 1) / nt;
                 if (nt == 512) stg = stg <= 12 ? 12 : (stg <= 14 ? 14 : (stg <= 16 ? 16 : 18)); else stg = stg_inst;
-                const int pt = static_cast<int>((s.ld + nt - 1) / nt);
+                const int pt = static_cast<int>((s.width + nt - 1) / nt);
                 int mc = fast_max_cpt(nt, stg);
                 if (env_cpt >= 4) mc = std::min(mc, env_cpt * (1024 / nt) / 4 * 4);
                 const int nch = (pt + mc - 1) / mc;
                 if (nch < f_chunks) { f_chunks = nch; f_nt = nt; f_stg = stg; }
             }
-            const int f_pt = static_cast<int>((s.ld + f_nt - 1) / f_nt);
+            const int f_pt = static_cast<int>((s.width + f_nt - 1) / f_nt);
             const int f_cpt = ((f_pt + f_chunks - 1) / f_chunks + 3) / 4 * 4;
             const long long f_items = static_cast<long long>(dg.n_groups) * f_chunks;
             // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
@@ -1974,8 +1962,36 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         if (kernel == 1) HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
         return GENPHI_OK;
     }
-    // 1. columns [0, nd) of every row: dragged rows are compacted copies, new rows compacted half sums
     const bool nn_naive = s.nn_naive || s.nn.empty();
+    if (n_new > 0 && !nn_naive) {
+        // 1. Psi_P = Psi[parents][parents], with its zero padding and "none" row, and its rows' certificates
+        const LevelStep &nn = s.nn[0];
+        const DeviceStep &dn = p->nn_dsteps[d.nn];
+        const int n_par = static_cast<int>(nn.n_prev);
+        HIP_TRY(hipMemsetAsync(p->d_cert_p, 0, (static_cast<size_t>(n_par) + 1) * sizeof(int), p->stream));
+        if (n_par > 0) {
+            dim3 grid(static_cast<unsigned>(n_par), static_cast<unsigned>((n_par + 2047) / 2048));
+            hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
+                               d.pardesc, d.parents, n_par, p->psi_p, static_cast<long long>(nn.ld_prev), p->d_cert_p, thr);
+        }
+        hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n_par + 1)), dim3(256), 0, p->stream, p->psi_p,
+                           static_cast<long long>(nn.ld_prev), n_par);
+        HIP_TRY(hipGetLastError());
+        // 2. the new x new block: a FULL / SPLIT level step on Psi_P, written IN PLACE.  The sub-step's
+        //    member lead + r is member nd + r of the cut, so its matrix starts (nd - lead) rows and
+        //    columns into the cut's; the `lead` placeholder columns (zeros) land on columns
+        //    [nd - lead, nd) of the new rows, which pass 3 overwrites.  The sub-step also writes the
+        //    zero padding [n, ld) of its rows.
+        const long long shift = nd - nn.lead;
+        LevelCtx cn;
+        cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
+        cn.cert_prev = p->d_cert_p;
+        cn.cert_out = cert_out + shift;
+        cn.identity = false; cn.dbg = false; cn.no_none_row = true;
+        const int rc = launch_level(p, cn, p->psi_p, out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
+        if (rc) return rc;
+    }
+    // 3. columns [0, nd) of every row: dragged rows are compacted copies, new rows compacted half sums
     const int rows_1 = nn_naive ? nd : n;                 // (naive fallback: the new rows come whole from the per-entry kernel)
     if (nd > 0 && rows_1 > 0) {
         dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));      // 256 threads x 8 elements
@@ -1987,38 +2003,11 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         if (nn_naive) {
             LevelArgs a;
             std::memset(&a, 0, sizeof(a));
-            a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.n_prev = none; a.n = n;
+            a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.width = static_cast<int>(s.ld); a.n_prev = none; a.n = n;
             a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.rows = d.newrows; a.n_rows = n_new;
             a.cert_out = cert_out; a.cert_thresh = thr;
             dim3 grid(static_cast<unsigned>(n_new), static_cast<unsigned>((s.ld + 255) / 256));
             hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
-            HIP_TRY(hipGetLastError());
-        } else {
-            // 2. Psi_P = Psi[parents][parents], with its zero padding and "none" row, and its rows' certificates
-            const LevelStep &nn = s.nn[0];
-            const DeviceStep &dn = p->nn_dsteps[d.nn];
-            const int n_par = static_cast<int>(nn.n_prev);
-            HIP_TRY(hipMemsetAsync(p->d_cert_p, 0, (static_cast<size_t>(n_par) + 1) * sizeof(int), p->stream));
-            if (n_par > 0) {
-                dim3 grid(static_cast<unsigned>(n_par), static_cast<unsigned>((n_par + 2047) / 2048));
-                hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
-                                   d.pardesc, d.parents, n_par, p->psi_p, static_cast<long long>(nn.ld_prev), p->d_cert_p, thr);
-            }
-            hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n_par + 1)), dim3(256), 0, p->stream, p->psi_p,
-                               static_cast<long long>(nn.ld_prev), n_par);
-            HIP_TRY(hipGetLastError());
-            // 3. the new x new block: a FULL / SPLIT level step on Psi_P into its own buffer
-            LevelCtx cn;
-            cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
-            cn.cert_prev = p->d_cert_p;
-            cn.cert_out = cert_out + nd;                                  // row r of the block is row nd + r of the cut
-            cn.identity = false; cn.dbg = false;
-            // (as an intermediate level of its own: the kernels also write the block's padding and "none" row)
-            const int rc = launch_level(p, cn, p->psi_p, p->nn_out, dn.work, nullptr, n_new, 0, dn.groups);
-            if (rc) return rc;
-            dim3 gc(static_cast<unsigned>(n_new), static_cast<unsigned>((n_new + 1023) / 1024));
-            hipLaunchKernelGGL(copy_block_kernel, gc, dim3(256), 0, p->stream, p->nn_out, static_cast<long long>(nn.ld), n_new, n_new,
-                               out, static_cast<long long>(s.ld), nd, nd);
             HIP_TRY(hipGetLastError());
         }
         // 4. dragged x new = (new x dragged)^T

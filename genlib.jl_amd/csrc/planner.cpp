@@ -326,7 +326,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         const int64_t n = plan.cut_sizes[c], n_prev = plan.cut_sizes[c - 1];
         const int32_t d = L - 1 - c;
         st.n_prev = n_prev; st.n = n;
-        st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
+        st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c]; st.width = st.ld;
         st.mode = mode_for(n_prev, opt);
         st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
         const int32_t none = static_cast<int32_t>(n_prev);
@@ -364,19 +364,29 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         if (nn_mode == kModeWide) { st.nn_naive = true; return; }
         st.nn.resize(1);
         LevelStep &nn = st.nn[0];
-        nn.n_prev = n_par; nn.n = n_new;
-        nn.ld_prev = pitch_for(n_par); nn.ld = pitch_for(n_new);
+        // written in place (rows / columns [dragged, n) of this cut's matrix): `lead` placeholder
+        // members in front put the block's first column on a 16-byte boundary of the rows
+        const int64_t lead = dragged % 4;
+        nn.lead = static_cast<int32_t>(lead);
+        nn.n_prev = n_par; nn.n = lead + n_new;
+        nn.ld_prev = pitch_for(n_par); nn.ld = st.ld; nn.width = st.ld - (dragged - lead);
         nn.mode = nn_mode;
-        nn.srcA.resize(n_new); nn.srcB.resize(n_new); nn.ord.resize(n_new);
+        nn.srcA.resize(nn.n); nn.srcB.resize(nn.n); nn.ord.resize(nn.n);
         const int32_t pnone = static_cast<int32_t>(n_par);
+        for (int64_t k = 0; k < lead; ++k) { nn.srcA[k] = nn.srcB[k] = pnone; nn.ord[k] = 0; }   // column of zeros, no row
         for (int64_t k = 0; k < n_new; ++k) {
             const int32_t A = st.srcA[dragged + k], B = st.srcB[dragged + k];
-            nn.srcA[k] = A == none ? pnone : pidx[A];
-            nn.srcB[k] = B == none ? pnone : pidx[B];
-            nn.ord[k] = st.ord[dragged + k];
+            nn.srcA[lead + k] = A == none ? pnone : pidx[A];
+            nn.srcB[lead + k] = B == none ? pnone : pidx[B];
+            nn.ord[lead + k] = st.ord[dragged + k];
         }
         nn.n_dragged = 0;
         finish_narrow_step(nn, w);
+        if (lead) {                    // the placeholders have no row
+            size_t o = 0;
+            for (int32_t r : nn.work) if (r >= lead) nn.work[o++] = r;
+            nn.work.resize(o);
+        }
     };
     // single-threaded by default: the steps are short and fresh threads cost more than they save on
     // small hosts (measured: 1 thread 0.10 s, 8 threads 0.12 s for cfg4); GENPHI_PLAN_THREADS overrides

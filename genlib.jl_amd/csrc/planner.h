@@ -43,6 +43,7 @@ enum { kModeFull = 0, kModeSplit = 1, kModeWide = 2 };
 struct LevelStep {
     int64_t n_prev = 0, n = 0;        // |cut s|, |cut s+1|
     int64_t ld_prev = 0, ld = 0;      // row pitch (floats) of the two level matrices
+    int64_t width = 0;                // columns a row kernel writes: [0, n) and the zero padding [n, width); = ld except in a sub-step
     int64_t n_dragged = 0;            // |cut s ∩ cut s+1|  ("both" in the verbose lines)
     // per member of cut s+1, in this cut's storage order:
     std::vector<int32_t> srcA, srcB;  // positions in cut s; n_prev = none
@@ -55,10 +56,14 @@ struct LevelStep {
     // WIDE only.  The cut is stored [dragged..., new...] (n_dragged, n - n_dragged).
     std::vector<int32_t> parents;     // distinct parents of the new members: positions in cut s, ascending
     // the new x new block as a level step of its own over Psi_P = Psi[parents][parents]:
-    // n_prev = |parents|, n = n_new, sources = indices into `parents` (|parents| = none); mode FULL
-    // or SPLIT (0 or 1 element; empty with nn_naive when |parents| is too wide even for SPLIT:
-    // the block then comes from the per-entry kernel on Psi itself)
+    // n_prev = |parents|, sources = indices into `parents` (|parents| = none); mode FULL or SPLIT
+    // (0 or 1 element; empty with nn_naive when |parents| is too wide even for SPLIT: the block then
+    // comes from the per-entry kernel on Psi itself).  The sub-step writes the block IN PLACE, into
+    // rows / columns [n_dragged, n) of the cut's matrix: its pitch is the cut's, and it starts with
+    // lead = n_dragged % 4 placeholder members (no sources, not in `work`) so that its column 0 sits
+    // on a 16-byte boundary of the cut's rows: n = lead + n_new, width = ld - (n_dragged - lead).
     std::vector<LevelStep> nn;
+    int32_t lead = 0;                 // (of a sub-step) placeholder members in front
     bool nn_naive = false;
 };
 
