@@ -881,24 +881,40 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
 // destination row that receives an uncertified value.  (128 x 128 tiles -- 512-byte runs on both
 // sides, 66 KB of LDS -- were measured 13 % slower on cfg4o: two workgroups per CU hide less latency.)
 constexpr int kTT = 64;
+// `shift` source rows of the first tile row are empty so that every destination run (64 floats) starts on
+// a 128-byte line although dst_col0 is arbitrary: runs that straddle lines are partial-line writes from
+// two workgroups at different times (same-box A/B on cfg4o: 367 -> 329 ms for the whole sweep,
+// profiles/microbench/out/r02_ab_transpose_line_aligned_cfg4o.out; 128-row tiles: no further gain).
 __global__ void __launch_bounds__(256)
 transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows, int cols, float *__restrict__ dst,
-                       long long ld_dst, int dst_col0, int *__restrict__ cert_out, unsigned cert_thresh)
+                       long long ld_dst, int dst_col0, int shift, int *__restrict__ cert_out, unsigned cert_thresh)
 {
-    __shared__ float tile[kTT][kTT + 1];
-    const int r0 = blockIdx.y * kTT, c0 = blockIdx.x * kTT;
+    constexpr int TR = kTT;
+    __shared__ float tile[TR][kTT + 1];
+    const int r0 = (int)blockIdx.y * TR - shift, c0 = blockIdx.x * kTT;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = ty; k < kTT; k += 4) {
-        const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.f;
+    for (int kb = ty; kb < TR; kb += 32) {                   // 8 loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = min(max(r0 + kb + 4 * u, 0), rows - 1), c = min(c0 + tx, cols - 1);     // clamped: unconditional loads
+            v[u] = src[(long long)r * ld_src + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tile[kb + 4 * u][tx] = v[u];
     }
     __syncthreads();
+#pragma unroll 4
     for (int k = ty; k < kTT; k += 4) {
-        const int c = c0 + k, r = r0 + tx;
-        if (c < cols && r < rows) {
-            const float v = tile[tx][k];
-            dst[(long long)c * ld_dst + dst_col0 + r] = v;
-            if (cert_out && cert_key(v) < cert_thresh) cert_out[c] = 1;
+        const int c = c0 + k;
+#pragma unroll
+        for (int h = 0; h < TR / 64; ++h) {
+            const int r = r0 + h * 64 + tx;
+            if (c < cols && r >= 0 && r < rows) {
+                const float v = tile[h * 64 + tx][k];
+                dst[(long long)c * ld_dst + dst_col0 + r] = v;
+                if (cert_out && cert_key(v) < cert_thresh) cert_out[c] = 1;
+            }
         }
     }
 }
@@ -2012,9 +2028,11 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         }
         // 4. dragged x new = (new x dragged)^T
         if (nd > 0) {
-            dim3 gt(static_cast<unsigned>((nd + kTT - 1) / kTT), static_cast<unsigned>((n_new + kTT - 1) / kTT));
+            static const bool tt_align = std::getenv("GENPHI_TT_NOALIGN") == nullptr;        // A/B hook
+            const int shift = tt_align ? (nd & 31) : 0;                     // destination runs start on 128-byte lines
+            dim3 gt(static_cast<unsigned>((nd + kTT - 1) / kTT), static_cast<unsigned>((n_new + shift + kTT - 1) / kTT));
             hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(nd) * s.ld,
-                               static_cast<long long>(s.ld), n_new, nd, out, static_cast<long long>(s.ld), nd, cert_out, thr);
+                               static_cast<long long>(s.ld), n_new, nd, out, static_cast<long long>(s.ld), nd, shift, cert_out, thr);
             HIP_TRY(hipGetLastError());
         }
     }

@@ -365,7 +365,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         st.nn.resize(1);
         LevelStep &nn = st.nn[0];
         // written in place (rows / columns [dragged, n) of this cut's matrix): `lead` placeholder
-        // members in front put the block's first column on a 16-byte boundary of the rows
+        // members in front put the block's first column on a 16-byte boundary of the rows (128-byte
+        // alignment measured no faster: profiles/microbench/out/r02_ab_nn_block_alignment_cfg4o.out)
         const int64_t lead = dragged % 4;
         nn.lead = static_cast<int32_t>(lead);
         nn.n_prev = n_par; nn.n = lead + n_new;
