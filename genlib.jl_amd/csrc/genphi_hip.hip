@@ -24,7 +24,10 @@
 //       passes: rows_compact_kernel (dragged x dragged = a stream compaction of the previous
 //       matrix; new x dragged = the compacted half sum of two rows; the parent x parent matrix),
 //       transpose_block_kernel (dragged x new), a FULL / SPLIT sub-step on the compacted parent
-//       matrix that writes the new x new block in place, pad_zero_kernel.
+//       matrix that writes the new x new block in place, pad_zero_kernel.  Levels with few dragged
+//       members: drag_rows_kernel (a dragged row whole, its new columns gathered from the row's
+//       parent entries in LDS) and the transpose the other way round -- the parent rows are not
+//       streamed for the new x dragged block.
 //   levels_small_kernel a RUN of consecutive steps with cuts <= 128 members in one persistent
 //       launch: both level matrices live in LDS, one barrier per level (deep small pedigrees
 //       are launch-bound otherwise).
@@ -876,6 +879,71 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
     if (cert_out && ck < cert_thresh) cert_out[d.z] = 1;
 }
 
+// The dragged rows of a WIDE level in ONE pass over their source row: row j of the cut is the row of
+// the same member in the previous cut,
+//   columns [0, nd)   out[j][k] = Psi[a_j][idx[k]]                           (stream compaction)
+//   columns [nd, n)   out[j][nd + i] = RN32((Psi[a_j][f_i] + Psi[a_j][m_i]) / 2)   (the dragged x new block)
+// The row's entries at the PARENTS' positions are compacted into LDS while the row streams by -- the
+// parents inside the source window of each chunk of 8 * NT output columns (pstart[c] .. pstart[c + 1]
+// of the ascending `parents` list), so the second touch of a sector comes from L1 / L2 -- and the new
+// columns are gathered from there: pkn[i] =
+// (parent index of f_i) | (of m_i) << 16, n_par = none (a zero).  One workgroup per row.
+template <int NT>
+__global__ void __launch_bounds__(NT)
+drag_rows_kernel(const float *__restrict__ psi, long long ld_prev, const int *__restrict__ idx, int nd,
+                 const int *__restrict__ parents, int n_par, const int *__restrict__ pstart, const unsigned *__restrict__ pkn,
+                 int n_new, float *__restrict__ out, long long ld_out, int *__restrict__ cert_out, unsigned cert_thresh)
+{
+    extern __shared__ float lds[];
+    float *P = lds;                                            // n_par + 1 floats
+    constexpr int U = 8;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const float *ra = psi + (long long)idx[j] * ld_prev;
+    float *o = out + (long long)j * ld_out;
+    unsigned ck = 0xffffffffu;
+    const int n_chunks = (nd + NT * U - 1) / (NT * U);
+    // (a version with two chunks in flight per wave, index words of chunk c + 2 and gathers of chunk
+    // c + 1 issued before chunk c is consumed, measured 2 % slower: the waves of a 1024-thread
+    // workgroup already overlap each other)
+    for (int c = 0; c < n_chunks; ++c) {
+        const int k0 = c * (NT * U) + tid;
+        int q[U];
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] = idx[min(k0 + u * NT, nd - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = ra[q[u]];
+        const int pe = pstart[c + 1];
+        for (int k = pstart[c] + tid; k < pe; k += NT) P[k] = ra[parents[k]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * NT;
+            if (k < nd) {
+                ck = min(ck, cert_key(a[u]));
+                __builtin_nontemporal_store(a[u], o + k);
+            }
+        }
+    }
+    if (tid == 0) P[n_par] = 0.f;
+    __syncthreads();
+    float *on = o + nd;
+    for (int i0 = tid; i0 < n_new; i0 += 4 * NT) {
+        unsigned w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = pkn[min(i0 + u * NT, n_new - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT;
+            const float v = static_cast<float>((static_cast<double>(P[w[u] & 0xffff]) + static_cast<double>(P[w[u] >> 16])) * 0.5);
+            if (i < n_new) {
+                ck = min(ck, cert_key(v));
+                __builtin_nontemporal_store(v, on + i);
+            }
+        }
+    }
+    if (cert_out && ck < cert_thresh) cert_out[j] = 1;
+}
+
 // dst[c][dst_col0 + r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS, both sides
 // coalesced): the dragged x new block from the new x dragged block.  Flags the certificate of every
 // destination row that receives an uncertified value.  (128 x 128 tiles -- 512-byte runs on both
@@ -1267,6 +1335,8 @@ struct DeviceStep {
     // and for the parent rows of Psi_P; the parents' positions; the new rows as a work list
     int4 *rowdesc = nullptr, *pardesc = nullptr;
     int *parents = nullptr, *newrows = nullptr;
+    int *pstart = nullptr;     // drag_rows_kernel: first parent of each chunk of 8192 / 4096 dragged columns (two tables)
+    int pstart_n[2] = {0, 0};
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -1549,7 +1619,7 @@ static int upload_plan(genphi_plan *p, int device)
         }
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
-                     al((s.n - s.n_dragged) * sizeof(int));
+                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al((s.n_dragged / 4096 + 2) * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
@@ -1590,6 +1660,22 @@ static int upload_plan(genphi_plan *p, int device)
             d.pardesc = reinterpret_cast<int4 *>(put(pd.data(), pd.size() * sizeof(int4)));
             d.parents = reinterpret_cast<int *>(put(s.parents.data(), s.parents.size() * sizeof(int)));
             d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
+            // drag_rows_kernel: parents inside the source window of each chunk of dragged columns
+            // (chunks of 8192 columns for 1024 threads, then of 4096 for 512)
+            std::vector<int> ps;
+            for (int t = 0; t < 2; ++t) {
+                const int64_t chunk = t == 0 ? 8192 : 4096, nch = (s.n_dragged + chunk - 1) / chunk;
+                const size_t base = ps.size();
+                d.pstart_n[t] = static_cast<int>(base);
+                ps.resize(base + nch + 1, 0);
+                size_t pi = 0;
+                for (int64_t c = 1; c < nch; ++c) {
+                    while (pi < s.parents.size() && s.parents[pi] < s.srcA[c * chunk]) ++pi;
+                    ps[base + c] = static_cast<int>(pi);
+                }
+                ps[base + nch] = static_cast<int>(s.parents.size());
+            }
+            d.pstart = reinterpret_cast<int *>(put(ps.data(), ps.size() * sizeof(int)));
             if (!s.nn.empty()) d.nn = nn_next++;
         }
     }
@@ -2007,16 +2093,54 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         const int rc = launch_level(p, cn, p->psi_p, out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
         if (rc) return rc;
     }
-    // 3. columns [0, nd) of every row: dragged rows are compacted copies, new rows compacted half sums
-    const int rows_1 = nn_naive ? nd : n;                 // (naive fallback: the new rows come whole from the per-entry kernel)
-    if (nd > 0 && rows_1 > 0) {
-        dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));      // 256 threads x 8 elements
-        hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
-                           d.rowdesc, d.srcA, nd, out, static_cast<long long>(s.ld), cert_out, thr);
+    // Two routes for the blocks that involve dragged members:
+    //   A  rows_compact_kernel on every row (dragged x dragged, new x dragged), then dragged x new as the
+    //      transpose of new x dragged.  The new rows stream two whole parent rows each to keep nd columns.
+    //   B  drag_rows_kernel: the dragged rows whole (compacted copy + the dragged x new block gathered from
+    //      the row's entries at the parents' positions, which sit in LDS), then new x dragged as the
+    //      transpose of dragged x new: the parent rows are not streamed at all, but the kernel is held to
+    //      one workgroup per CU by its LDS and streams ~20 % slower than the 2-D grid of route A.
+    //   B wins when new members are many and dragged ones few (the late levels of overlapping generations).
+    //   Per level of cfg4o (profiles/microbench/out/r02_ab_wide_route_per_level_cfg4o.out) B is faster from
+    //   nd / n_prev ~ 0.63 downwards (the level at 0.29: 4.05 -> 3.65 ms), slower above (the widest level:
+    //   25.1 -> 29.1 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 5/8.
+    const char *route_env = std::getenv("GENPHI_WIDE_ROUTE");            // (read per launch: the tests switch it between plans)
+    bool route_b = !nn_naive && nd > 0 && n_new > 0 && s.nn[0].n_prev > 0;
+    if (route_b) route_b = route_env ? (route_env[0] == 'B' || route_env[0] == 'b') : (8LL * nd < 5LL * s.n_prev);
+    if (route_b) {
+        // 3B. the dragged rows, all n columns
+        const LevelStep &nn = s.nn[0];
+        const DeviceStep &dn = p->nn_dsteps[d.nn];
+        const int n_par = static_cast<int>(nn.n_prev);
+        const size_t lds = (static_cast<size_t>(n_par) + 4) / 4 * 4 * sizeof(float);
+        const unsigned *pkn = dn.pk + nn.lead;
+        if (lds <= 78 * 1024) {                                                 // two workgroups per CU fit
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(drag_rows_kernel<512>), lds));
+            hipLaunchKernelGGL(drag_rows_kernel<512>, dim3(static_cast<unsigned>(nd)), dim3(512), lds, p->stream, psi,
+                               static_cast<long long>(s.ld_prev), d.srcA, nd, d.parents, n_par, d.pstart + d.pstart_n[1], pkn, n_new, out,
+                               static_cast<long long>(s.ld), cert_out, thr);
+        } else {
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(drag_rows_kernel<1024>), lds));
+            hipLaunchKernelGGL(drag_rows_kernel<1024>, dim3(static_cast<unsigned>(nd)), dim3(1024), lds, p->stream, psi,
+                               static_cast<long long>(s.ld_prev), d.srcA, nd, d.parents, n_par, d.pstart + d.pstart_n[0], pkn, n_new, out,
+                               static_cast<long long>(s.ld), cert_out, thr);
+        }
         HIP_TRY(hipGetLastError());
-    }
-    if (n_new > 0) {
-        if (nn_naive) {
+        // 4B. new x dragged = (dragged x new)^T: destination runs start at column 0 (aligned)
+        dim3 gt(static_cast<unsigned>((n_new + kTT - 1) / kTT), static_cast<unsigned>((nd + kTT - 1) / kTT));
+        hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + nd, static_cast<long long>(s.ld), nd, n_new,
+                           out + static_cast<long long>(nd) * s.ld, static_cast<long long>(s.ld), 0, 0, cert_out + nd, thr);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // 3A. columns [0, nd) of every row: dragged rows are compacted copies, new rows compacted half sums
+        const int rows_1 = nn_naive ? nd : n;                 // (naive fallback: the new rows come whole from the per-entry kernel)
+        if (nd > 0 && rows_1 > 0) {
+            dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));      // 256 threads x 8 elements
+            hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
+                               d.rowdesc, d.srcA, nd, out, static_cast<long long>(s.ld), cert_out, thr);
+            HIP_TRY(hipGetLastError());
+        }
+        if (n_new > 0 && nn_naive) {
             LevelArgs a;
             std::memset(&a, 0, sizeof(a));
             a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.width = static_cast<int>(s.ld); a.n_prev = none; a.n = n;
@@ -2026,8 +2150,8 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
             hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
             HIP_TRY(hipGetLastError());
         }
-        // 4. dragged x new = (new x dragged)^T
-        if (nd > 0) {
+        // 4A. dragged x new = (new x dragged)^T
+        if (n_new > 0 && nd > 0) {
             static const bool tt_align = std::getenv("GENPHI_TT_NOALIGN") == nullptr;        // A/B hook
             const int shift = tt_align ? (nd & 31) : 0;                     // destination runs start on 128-byte lines
             dim3 gt(static_cast<unsigned>((nd + kTT - 1) / kTT), static_cast<unsigned>((n_new + shift + kTT - 1) / kTT));

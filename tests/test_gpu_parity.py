@@ -556,7 +556,8 @@ def test_wide_levels_block_assembly(gen, oracle, monkeypatch):
     """WIDE steps (a source row does not fit in LDS; forced here by shrinking the LDS budget): the
     level is assembled from row compaction (dragged x dragged, new x dragged), a transpose (dragged x
     new) and a FULL / SPLIT sub-step on the compacted parent matrix (new x new) -- or the per-entry
-    kernel when the parents are too many as well.  Overlapping generations (most of a cut is dragged
+    kernel when the parents are too many as well; with few dragged members the dragged rows come whole
+    from drag_rows_kernel and the transpose runs the other way (both routes forced here).  Overlapping generations (most of a cut is dragged
     along), a WIDE last step (proband-order delivery), row shards, certificates on and off."""
     from genlib_jl_amd import synth
     seen_nn = set()
@@ -571,8 +572,9 @@ def test_wide_levels_block_assembly(gen, oracle, monkeypatch):
         ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
         ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
         want = oracle.Pedigree(ind, fa, mo).phi(pro)
-        for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-5"}):
-            for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP"):
+        for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-5"}, {"GENPHI_WIDE_ROUTE": "A"},
+                    {"GENPHI_WIDE_ROUTE": "B", "GENPHI_CERT_MIN_EXP": "-5"}):
+            for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_WIDE_ROUTE"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -587,7 +589,7 @@ def test_wide_levels_block_assembly(gen, oracle, monkeypatch):
             _assert_equal(np.concatenate(parts, axis=0), want)
             pl.close()
     assert {0, 1, 3} <= seen_nn, seen_nn          # FULL, SPLIT and per-entry new x new blocks all exercised
-    for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS"):
+    for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_WIDE_ROUTE"):
         monkeypatch.delenv(k, raising=False)
 
 
