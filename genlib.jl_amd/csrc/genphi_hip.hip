@@ -887,7 +887,12 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
 // parents inside the source window of each chunk of 8 * NT output columns (pstart[c] .. pstart[c + 1]
 // of the ascending `parents` list), so the second touch of a sector comes from L1 / L2 -- and the new
 // columns are gathered from there: pkn[i] =
-// (parent index of f_i) | (of m_i) << 16, n_par = none (a zero).  One workgroup per row.
+// (parent index of f_i) | (of m_i) << 16, n_par = none (a zero).
+// Persistent and software-pipelined: a workgroup walks rows blockIdx.x, + gridDim.x, ...; its work
+// units (row, chunk) form ONE stream with the index words two units ahead and the gathers one
+// unit ahead of the unit being consumed -- across row boundaries too, so the start-up of a row (row
+// pointer, first index words, first gathers) and its LDS-gather phase overlap the neighbouring rows'
+// loads.  With one workgroup per CU (LDS) nothing else would hide them.
 template <int NT>
 __global__ void __launch_bounds__(NT)
 drag_rows_kernel(const float *__restrict__ psi, long long ld_prev, const int *__restrict__ idx, int nd,
@@ -896,52 +901,98 @@ drag_rows_kernel(const float *__restrict__ psi, long long ld_prev, const int *__
 {
     extern __shared__ float lds[];
     float *P = lds;                                            // n_par + 1 floats
-    constexpr int U = 8;
-    const int j = blockIdx.x, tid = threadIdx.x;
-    const float *ra = psi + (long long)idx[j] * ld_prev;
-    float *o = out + (long long)j * ld_out;
-    unsigned ck = 0xffffffffu;
+    constexpr int U = 8, PU = 4;
+    const int tid = threadIdx.x, nb = gridDim.x;
     const int n_chunks = (nd + NT * U - 1) / (NT * U);
-    // (a version with two chunks in flight per wave, index words of chunk c + 2 and gathers of chunk
-    // c + 1 issued before chunk c is consumed, measured 2 % slower: the waves of a 1024-thread
-    // workgroup already overlap each other)
-    for (int c = 0; c < n_chunks; ++c) {
-        const int k0 = c * (NT * U) + tid;
-        int q[U];
-        float a[U];
+    struct Unit { int row, c; };                               // wave-uniform
+    auto next = [&](Unit u) { Unit v; v.c = u.c + 1 == n_chunks ? 0 : u.c + 1; v.row = u.c + 1 == n_chunks ? u.row + nb : u.row; return v; };
+    int qA[U], qB[U], pqA[PU], pqB[PU], srA, srB;              // index words, source row of the unit
+    float aA[U], aB[U], paA[PU], paB[PU];
+    auto issue_idx = [&](Unit u, int (&q)[U], int (&pq)[PU], int &sr) {
+        const int row = min(u.row, nd - 1);                    // past the end: harmless duplicate loads
+        sr = idx[row];
+        const int k0 = u.c * (NT * U) + tid;
 #pragma unroll
-        for (int u = 0; u < U; ++u) q[u] = idx[min(k0 + u * NT, nd - 1)];
+        for (int e = 0; e < U; ++e) q[e] = idx[min(k0 + e * NT, nd - 1)];
+        const int pb = pstart[u.c];
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = ra[q[u]];
-        const int pe = pstart[c + 1];
-        for (int k = pstart[c] + tid; k < pe; k += NT) P[k] = ra[parents[k]];
+        for (int e = 0; e < PU; ++e) pq[e] = parents[min(pb + tid + e * NT, n_par - 1)];
+    };
+    auto issue_gather = [&](const int (&q)[U], const int (&pq)[PU], int sr, float (&a)[U], float (&pa)[PU]) {
+        const float *ra = psi + (long long)__builtin_amdgcn_readfirstlane(sr) * ld_prev;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + u * NT;
+        for (int e = 0; e < U; ++e) a[e] = ra[q[e]];
+#pragma unroll
+        for (int e = 0; e < PU; ++e) pa[e] = ra[pq[e]];
+    };
+    unsigned ck = 0xffffffffu;
+    auto consume = [&](Unit u, const float (&a)[U], const float (&pa)[PU], int sr) {
+        if (u.row >= nd) return;
+        float *o = out + (long long)u.row * ld_out;
+        const int k0 = u.c * (NT * U) + tid;
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const int k = k0 + e * NT;
             if (k < nd) {
-                ck = min(ck, cert_key(a[u]));
-                __builtin_nontemporal_store(a[u], o + k);
+                ck = min(ck, cert_key(a[e]));
+                __builtin_nontemporal_store(a[e], o + k);
             }
         }
-    }
-    if (tid == 0) P[n_par] = 0.f;
-    __syncthreads();
-    float *on = o + nd;
-    for (int i0 = tid; i0 < n_new; i0 += 4 * NT) {
-        unsigned w[4];
+        const int pb = pstart[u.c], pe = pstart[u.c + 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = pkn[min(i0 + u * NT, n_new - 1)];
+        for (int e = 0; e < PU; ++e) {
+            const int k = pb + tid + e * NT;
+            if (k < pe) P[k] = pa[e];
+        }
+        if (pe - pb > PU * NT) {                               // a window with many parents (few dragged columns)
+            const float *ra = psi + (long long)__builtin_amdgcn_readfirstlane(sr) * ld_prev;
+            for (int k = pb + PU * NT + tid; k < pe; k += NT) P[k] = ra[parents[k]];
+        }
+        if (u.c + 1 < n_chunks) return;
+        // last chunk of the row: the new columns from the parent entries in LDS
+        if (tid == 0) P[n_par] = 0.f;
+        __syncthreads();
+        float *on = o + nd;
+        for (int i0 = tid; i0 < n_new; i0 += 4 * NT) {
+            unsigned w[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * NT;
-            const float v = static_cast<float>((static_cast<double>(P[w[u] & 0xffff]) + static_cast<double>(P[w[u] >> 16])) * 0.5);
-            if (i < n_new) {
-                ck = min(ck, cert_key(v));
-                __builtin_nontemporal_store(v, on + i);
+            for (int e = 0; e < 4; ++e) w[e] = pkn[min(i0 + e * NT, n_new - 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * NT;
+                const float v = static_cast<float>((static_cast<double>(P[w[e] & 0xffff]) + static_cast<double>(P[w[e] >> 16])) * 0.5);
+                if (i < n_new) {
+                    ck = min(ck, cert_key(v));
+                    __builtin_nontemporal_store(v, on + i);
+                }
             }
         }
+        if (cert_out && ck < cert_thresh) cert_out[u.row] = 1;
+        ck = 0xffffffffu;
+        __syncthreads();                                       // P is rewritten by the next row's units
+    };
+    Unit u0; u0.row = blockIdx.x; u0.c = 0;
+    if (u0.row >= nd) return;
+    Unit u1 = next(u0);
+    issue_idx(u0, qA, pqA, srA);
+    issue_idx(u1, qB, pqB, srB);
+    issue_gather(qA, pqA, srA, aA, paA);
+    for (;;) {
+        // in flight: gathers of u0 (set A), index words of u1 (set B)
+        const int s0 = srA;
+        Unit u2 = next(u1);
+        issue_idx(u2, qA, pqA, srA);
+        issue_gather(qB, pqB, srB, aB, paB);
+        consume(u0, aA, paA, s0);
+        if (u1.row >= nd) break;
+        const int s1 = srB;
+        Unit u3 = next(u2);
+        issue_idx(u3, qB, pqB, srB);
+        issue_gather(qA, pqA, srA, aA, paA);
+        consume(u1, aB, paB, s1);
+        if (u2.row >= nd) break;
+        u0 = u2; u1 = u3;
     }
-    if (cert_out && ck < cert_thresh) cert_out[j] = 1;
 }
 
 // dst[c][dst_col0 + r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS, both sides
@@ -1335,8 +1386,7 @@ struct DeviceStep {
     // and for the parent rows of Psi_P; the parents' positions; the new rows as a work list
     int4 *rowdesc = nullptr, *pardesc = nullptr;
     int *parents = nullptr, *newrows = nullptr;
-    int *pstart = nullptr;     // drag_rows_kernel: first parent of each chunk of 8192 / 4096 dragged columns (two tables)
-    int pstart_n[2] = {0, 0};
+    int *pstart = nullptr;     // drag_rows_kernel: first parent of each chunk of 8192 dragged columns
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -1619,7 +1669,7 @@ static int upload_plan(genphi_plan *p, int device)
         }
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
-                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al((s.n_dragged / 4096 + 2) * sizeof(int));
+                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
@@ -1660,21 +1710,15 @@ static int upload_plan(genphi_plan *p, int device)
             d.pardesc = reinterpret_cast<int4 *>(put(pd.data(), pd.size() * sizeof(int4)));
             d.parents = reinterpret_cast<int *>(put(s.parents.data(), s.parents.size() * sizeof(int)));
             d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
-            // drag_rows_kernel: parents inside the source window of each chunk of dragged columns
-            // (chunks of 8192 columns for 1024 threads, then of 4096 for 512)
-            std::vector<int> ps;
-            for (int t = 0; t < 2; ++t) {
-                const int64_t chunk = t == 0 ? 8192 : 4096, nch = (s.n_dragged + chunk - 1) / chunk;
-                const size_t base = ps.size();
-                d.pstart_n[t] = static_cast<int>(base);
-                ps.resize(base + nch + 1, 0);
-                size_t pi = 0;
-                for (int64_t c = 1; c < nch; ++c) {
-                    while (pi < s.parents.size() && s.parents[pi] < s.srcA[c * chunk]) ++pi;
-                    ps[base + c] = static_cast<int>(pi);
-                }
-                ps[base + nch] = static_cast<int>(s.parents.size());
+            // drag_rows_kernel: parents inside the source window of each chunk of 8192 dragged columns
+            const int64_t chunk = 8192, nch = (s.n_dragged + chunk - 1) / chunk;
+            std::vector<int> ps(nch + 1, 0);
+            size_t pi = 0;
+            for (int64_t c = 1; c < nch; ++c) {
+                while (pi < s.parents.size() && s.parents[pi] < s.srcA[c * chunk]) ++pi;
+                ps[c] = static_cast<int>(pi);
             }
+            ps[nch] = static_cast<int>(s.parents.size());
             d.pstart = reinterpret_cast<int *>(put(ps.data(), ps.size() * sizeof(int)));
             if (!s.nn.empty()) d.nn = nn_next++;
         }
@@ -2099,14 +2143,14 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     //   B  drag_rows_kernel: the dragged rows whole (compacted copy + the dragged x new block gathered from
     //      the row's entries at the parents' positions, which sit in LDS), then new x dragged as the
     //      transpose of dragged x new: the parent rows are not streamed at all, but the kernel is held to
-    //      one workgroup per CU by its LDS and streams ~20 % slower than the 2-D grid of route A.
+    //      one workgroup per CU by its LDS and streams ~25 % slower than the 2-D grid of route A.
     //   B wins when new members are many and dragged ones few (the late levels of overlapping generations).
     //   Per level of cfg4o (profiles/microbench/out/r02_ab_wide_route_per_level_cfg4o.out) B is faster from
-    //   nd / n_prev ~ 0.63 downwards (the level at 0.29: 4.05 -> 3.65 ms), slower above (the widest level:
-    //   25.1 -> 29.1 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 5/8.
+    //   nd / n_prev ~ 0.67 downwards (the level at 0.29: 4.07 -> 3.52 ms), slower above (the widest level:
+    //   24.9 -> 27.8 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 2/3.
     const char *route_env = std::getenv("GENPHI_WIDE_ROUTE");            // (read per launch: the tests switch it between plans)
     bool route_b = !nn_naive && nd > 0 && n_new > 0 && s.nn[0].n_prev > 0;
-    if (route_b) route_b = route_env ? (route_env[0] == 'B' || route_env[0] == 'b') : (8LL * nd < 5LL * s.n_prev);
+    if (route_b) route_b = route_env ? (route_env[0] == 'B' || route_env[0] == 'b') : (3LL * nd < 2LL * s.n_prev);
     if (route_b) {
         // 3B. the dragged rows, all n columns
         const LevelStep &nn = s.nn[0];
@@ -2114,17 +2158,11 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         const int n_par = static_cast<int>(nn.n_prev);
         const size_t lds = (static_cast<size_t>(n_par) + 4) / 4 * 4 * sizeof(float);
         const unsigned *pkn = dn.pk + nn.lead;
-        if (lds <= 78 * 1024) {                                                 // two workgroups per CU fit
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(drag_rows_kernel<512>), lds));
-            hipLaunchKernelGGL(drag_rows_kernel<512>, dim3(static_cast<unsigned>(nd)), dim3(512), lds, p->stream, psi,
-                               static_cast<long long>(s.ld_prev), d.srcA, nd, d.parents, n_par, d.pstart + d.pstart_n[1], pkn, n_new, out,
-                               static_cast<long long>(s.ld), cert_out, thr);
-        } else {
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(drag_rows_kernel<1024>), lds));
-            hipLaunchKernelGGL(drag_rows_kernel<1024>, dim3(static_cast<unsigned>(nd)), dim3(1024), lds, p->stream, psi,
-                               static_cast<long long>(s.ld_prev), d.srcA, nd, d.parents, n_par, d.pstart + d.pstart_n[0], pkn, n_new, out,
-                               static_cast<long long>(s.ld), cert_out, thr);
-        }
+        HIP_TRY(set_max_lds(reinterpret_cast<const void *>(drag_rows_kernel<1024>), lds));
+        const int grid = std::min(nd, p->n_cus * (lds <= 78 * 1024 ? 2 : 1));            // persistent
+        hipLaunchKernelGGL(drag_rows_kernel<1024>, dim3(static_cast<unsigned>(grid)), dim3(1024), lds, p->stream, psi,
+                           static_cast<long long>(s.ld_prev), d.srcA, nd, d.parents, n_par, d.pstart, pkn, n_new, out,
+                           static_cast<long long>(s.ld), cert_out, thr);
         HIP_TRY(hipGetLastError());
         // 4B. new x dragged = (dragged x new)^T: destination runs start at column 0 (aligned)
         dim3 gt(static_cast<unsigned>((n_new + kTT - 1) / kTT), static_cast<unsigned>((nd + kTT - 1) / kTT));
