@@ -10,7 +10,7 @@ for rep in 1 2 3; do
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json")); l = d["config"]["level_ms"]
-print(sys.argv[1].split("/")[-1], round(d["ms_per_step"], 2), "upper", round(sum(l[1:24]) / 23, 4) if len(l) > 25 else "", "final", round(l[-1], 3))
+print(sys.argv[1].split("/")[-1], round(d["ms_per_step"], 4), "upper", round(sum(l[1:24]) / 23, 4) if len(l) > 25 else "", "final", round(l[-1], 3))
 PY
   done
 done
