@@ -529,6 +529,37 @@ def test_certified_rows_fast_path_and_mixed_levels(gen, oracle, monkeypatch):
             monkeypatch.delenv(k, raising=False)
 
 
+def test_rows_of_several_column_chunks(gen, oracle, monkeypatch):
+    """Rows wider than one workgroup's columns are cut into column chunks (cfg4's final level: 4 chunks; work
+    item = sibling group x chunk).  Forced here on 6500 probands by the columns-per-thread hook, so that every
+    level has 2 chunks: certified and mixed levels, the grouping-exact kernel alone, 512- and 1024-thread
+    variants, row shards -- all bit-equal to the oracle."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(30000, 6500, 5, skip_permille=20)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    knobs = ("GENPHI_FAST_NT", "GENPHI_MAX_CPT", "GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST")
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")                      # every level is SPLIT
+    for env in ({"GENPHI_MAX_CPT": "4"},
+                {"GENPHI_MAX_CPT": "4", "GENPHI_FAST_NT": "512"},
+                {"GENPHI_MAX_CPT": "4", "GENPHI_FAST_NT": "512", "GENPHI_CERT_MIN_EXP": "-6"},
+                {"GENPHI_MAX_CPT": "4", "GENPHI_CERT_MIN_EXP": "-4"},
+                {"GENPHI_MAX_CPT": "4", "GENPHI_NO_FAST": "1"}):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, pro)
+        assert set(pl.step_modes()) == {1}
+        _assert_equal(pl.compute(), want)
+        n = len(want)
+        parts = [pl.compute(rows=r) for r in [(0, 1000), (1000, 1001), (1001, n)]]
+        _assert_equal(np.concatenate(parts, axis=0), want)
+        pl.close()
+    for k in knobs + ("GENPHI_FULL_MAX_FLOATS",):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_graph_replay_survives_shard_changes_and_release(gen, oracle):
     """A captured hipGraph bakes device pointers in; every reallocation (another shard, a larger
     result) must retire it.  Sequence A, A, B, A, A with a larger shard B in between, then a
