@@ -677,7 +677,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             dsc = desc[w];
             nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
         }
-        __syncthreads();                                // previous gathers are done with the buffer
+        // (the hand-over slot read below was written at least one barrier ago: stage A of the previous item)
         if (stage_is_a && kc > 0) {
             nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
             have_next = nxt_l < n_items;
@@ -686,12 +686,9 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
         const int gn = p.glist ? p.glist[gkn] : gkn;
         const int nextAi = grp[gn].y;
-#pragma unroll
-        for (int k_ = 0; k_ < STG; ++k_)
-            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
-        __syncthreads();
-
-        // ---- part 1: index loads (before the prefetch: vmcnt retires in order), next stage's row ----
+        // index loads and the queue draw BEFORE the prefetch (vmcnt retires in order); the prefetch itself
+        // is issued piece by piece as the LDS writes free the staging registers, so it leads by the LDS
+        // writes and the second barrier
         if (stage_is_a) {
             if (threadIdx.x == 0) slot[kc & 1] = draw();
             ++kc;
@@ -701,11 +698,16 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
                 pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
             }
         }
+        __syncthreads();                                // previous gathers are done with the buffer
         {
             const float *src = p.psi + (long long)(nextB != p.n_prev ? nextB : nextAi) * p.ld_prev;
 #pragma unroll
-            for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+            for (int k_ = 0; k_ < STG; ++k_) {
+                *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
+                pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+            }
         }
+        __syncthreads();
 
         // ---- part 2: gathers from the staged row ----
         int wfin_b, wfin_e;
