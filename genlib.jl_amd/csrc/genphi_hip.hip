@@ -610,7 +610,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 // Bit-identical to the grouping-exact kernel on certified rows (tests force both on the same input).
 template <int NTHREADS, int CPT, int STG, bool CERT>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, int *queue)
+level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int *__restrict__ glist,
+                        int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -653,7 +654,9 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
     int it = cur_l;
     int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
     int chunk = it - gk * p.n_chunks;
-    int g = p.glist ? p.glist[gk] : gk;
+    // (glist is a kernel argument of its own, const and restrict: its loads are scalar.  Read through the
+    // argument struct they were vector loads, and waiting for one drains vmcnt -- row stores included)
+    int g = glist[gk];
     int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
     int w = wb;
     bool stage_is_a = true;
@@ -684,7 +687,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         }
         const int next_item = nxt_l;
         const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
-        const int gn = p.glist ? p.glist[gkn] : gkn;
+        const int gn = glist[gkn];
         const int nextAi = grp[gn].y;
         // index loads and the queue draw BEFORE the prefetch (vmcnt retires in order); the prefetch itself
         // is issued piece by piece as the LDS writes free the staging registers, so it leads by the LDS
@@ -1867,7 +1870,7 @@ static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, con
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, queue);
+    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, a.glist, queue);
     return hipGetLastError();
 }
 
