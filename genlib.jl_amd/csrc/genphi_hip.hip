@@ -315,7 +315,7 @@ __device__ unsigned long long g_wg_phase[2][1024][16];   // [thread 0 | last thr
 
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, int *queue)
+level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int *__restrict__ glist, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -387,7 +387,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     int it = cur_l;                                       // current item
     int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
     int chunk = it - gk * p.n_chunks;
-    int g = p.glist ? p.glist[gk] : gk;
+    int g = glist ? glist[gk] : gk;                       // (a restrict kernel argument: scalar loads, see level_split_fast_kernel)
     int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
     int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
@@ -432,11 +432,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 #if GENPHI_WG_TIMES
         ph_b = stage_is_a ? 0 : 8;
 #endif
-        __syncthreads();                                // previous gathers are done with the buffer
-        GENPHI_PHASE(0);
+        // (the hand-over slot read below was written at least one barrier ago: stage A of the previous item)
         if (stage_is_a && kc > 0) {
-            // the item after next was drawn by thread 0 during the previous item's stage A; the
-            // barrier above orders that LDS write before this read
             nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
             have_next = nxt_l < n_items;
         }
@@ -444,20 +441,11 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         // (a dummy row when nothing is left: an unconditional prefetch keeps `pre` in one set)
         const int next_item = nxt_l;
         const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
-        const int gn = p.glist ? p.glist[gkn] : gkn;
+        const int gn = glist ? glist[gkn] : gkn;
         const int nextAi = grp[gn].y;
-#pragma unroll
-        for (int k_ = 0; k_ < STG; ++k_)
-            *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
-        GENPHI_PHASE(1);                                // wait for the prefetched row + LDS writes issued
-        __syncthreads();
-        GENPHI_PHASE(2);
-#if GENPHI_WG_TIMES
-        if (threadIdx.x == 0 || threadIdx.x == NT - 1) atomicAdd(&dbgl[(threadIdx.x ? 16 : 0) + (stage_is_a ? 6 : 7)], 1u);
-#endif
-
-        // ---- part 1: index loads of this stage (issued BEFORE the prefetch: vmcnt retires in
-        //      order, so the gathers below only wait for these) and the next stage's source ----
+        // ---- part 1: index loads of this stage and the queue draw, BEFORE the prefetch (vmcnt retires in
+        //      order, so the gathers below only wait for these) and before the first barrier: their
+        //      registers are dead here, and the prefetch can then follow the LDS writes piece by piece ----
         if (stage_is_a) {
             // the item after next: drawn now by thread 0 (oldest memory op of the stage, so
             // waiting for it never waits for the prefetch), read by everyone one item later
@@ -493,11 +481,23 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
             }
         }
+        __syncthreads();                                // previous gathers are done with the buffer
+        GENPHI_PHASE(0);
         {
+            // every staging register is reloaded with the next row's piece as soon as its LDS write has read it
             const float *src = p.psi + (long long)(nextB != p.n_prev ? nextB : nextAi) * p.ld_prev;
 #pragma unroll
-            for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+            for (int k_ = 0; k_ < STG; ++k_) {
+                *reinterpret_cast<f4_t *>(reinterpret_cast<char *>(sR) + (tl + k_ * NT) * 16u) = pre[k_];
+                pre[k_] = ld_off<f4_t>(src, (tl + k_ * NT) * 16u);
+            }
         }
+        GENPHI_PHASE(1);                                // wait for the prefetched row + LDS writes + next prefetch issued
+        __syncthreads();
+        GENPHI_PHASE(2);
+#if GENPHI_WG_TIMES
+        if (threadIdx.x == 0 || threadIdx.x == NT - 1) atomicAdd(&dbgl[(threadIdx.x ? 16 : 0) + (stage_is_a ? 6 : 7)], 1u);
+#endif
 
         GENPHI_PHASE(3);                                // index loads + prefetch issue
         // ---- part 2: gathers from the staged row ----
@@ -1838,7 +1838,7 @@ static hipError_t launch_split_inst(int grid, size_t lds, hipStream_t stream, co
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_kernel<1024, C, S, O>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_kernel<1024, C, S, O>), dim3(grid), dim3(1024), lds, stream, a, desc, grp, queue);
+    hipLaunchKernelGGL((level_split_kernel<1024, C, S, O>), dim3(grid), dim3(1024), lds, stream, a, desc, grp, a.glist, queue);
     return hipGetLastError();
 }
 
@@ -1852,7 +1852,7 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
 #else
     GENPHI_T(8, 2); GENPHI_T(16, 2); GENPHI_T(24, 2);
     GENPHI_T(8, 4); GENPHI_T(16, 4); GENPHI_T(24, 4);
-    GENPHI_T(8, 6); GENPHI_T(16, 6); GENPHI_T(20, 6); GENPHI_T(24, 6);
+    GENPHI_T(8, 6); GENPHI_T(16, 6); GENPHI_T(20, 6); if constexpr (O) { GENPHI_T(24, 6); }
     GENPHI_T(8, 7); GENPHI_T(16, 7); GENPHI_T(20, 7); if constexpr (O) { GENPHI_T(24, 7); }
     GENPHI_T(8, 8); GENPHI_T(16, 8); GENPHI_T(20, 8);
     GENPHI_T(8, 9); GENPHI_T(16, 9);
@@ -2025,7 +2025,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
         // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
         int max_cpt;
         if (s.pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
-        else           max_cpt = stg_inst <= 6 ? 24 : (stg_inst <= 8 ? 20 : 16);
+        else           max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 8 ? 20 : 16);
         const int env_cpt = std::getenv("GENPHI_MAX_CPT") ? std::atoi(std::getenv("GENPHI_MAX_CPT")) : 0;   // tuning hook: smaller chunks
         if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
