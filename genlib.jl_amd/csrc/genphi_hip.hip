@@ -1898,7 +1898,7 @@ static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hi
     GENPHI_F(1024, 8, 9); GENPHI_F(1024, 20, 9);
     GENPHI_F(512, 32, 12); GENPHI_F(512, 48, 12);
     GENPHI_F(512, 32, 14); GENPHI_F(512, 56, 14);
-    GENPHI_F(512, 32, 16); GENPHI_F(512, 56, 16);
+    GENPHI_F(512, 32, 16); GENPHI_F(512, 52, 16); GENPHI_F(512, 56, 16);
     GENPHI_F(512, 32, 18); GENPHI_F(512, 48, 18);
 #endif
 #undef GENPHI_F
