@@ -358,6 +358,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     __syncthreads();
     int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);  // this item / the next one (global item indices)
     int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
+    __syncthreads();                                      // thread 0 rewrites slot[0] in its first stage, ahead of that stage's first barrier
 #if GENPHI_WG_TIMES
     const unsigned long long t_start = wall_clock64();
     if (threadIdx.x == 0 && p.dbg) { g_wg_times[blockIdx.x][0] = t_start; g_wg_times[blockIdx.x][1] = t_start; g_wg_times[blockIdx.x][2] = 0; g_wg_clk[blockIdx.x][0] = clock64(); }
@@ -641,6 +642,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
     __syncthreads();
     int cur_l = __builtin_amdgcn_readfirstlane(slot[0]);
     int nxt_l = __builtin_amdgcn_readfirstlane(slot[1]);
+    __syncthreads();                                      // thread 0 rewrites slot[0] in its first stage, ahead of that stage's first barrier
     if (cur_l >= n_items) return;
     int kc = 0;
     unsigned tl = threadIdx.x;
