@@ -1881,7 +1881,7 @@ static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, con
 static int fast_max_cpt(int nt, int stg)
 {
     if (nt == 1024) return stg <= 4 ? 28 : (stg <= 8 ? 24 : 20);
-    return stg <= 12 ? 48 : (stg <= 16 ? 56 : 48);
+    return stg <= 12 ? 52 : (stg <= 16 ? 56 : 48);
 }
 
 template <bool CERT>
@@ -1898,7 +1898,7 @@ static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hi
     GENPHI_F(1024, 8, 7); GENPHI_F(1024, 16, 7); GENPHI_F(1024, 24, 7);
     GENPHI_F(1024, 8, 8); GENPHI_F(1024, 16, 8); GENPHI_F(1024, 24, 8);
     GENPHI_F(1024, 8, 9); GENPHI_F(1024, 20, 9);
-    GENPHI_F(512, 32, 12); GENPHI_F(512, 48, 12);
+    GENPHI_F(512, 32, 12); GENPHI_F(512, 48, 12); GENPHI_F(512, 52, 12);
     GENPHI_F(512, 32, 14); GENPHI_F(512, 56, 14);
     GENPHI_F(512, 32, 16); GENPHI_F(512, 52, 16); GENPHI_F(512, 56, 16);
     GENPHI_F(512, 32, 18); GENPHI_F(512, 48, 18);
