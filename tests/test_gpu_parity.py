@@ -266,22 +266,36 @@ def test_row_shards_compute_only_their_ancestors(gen, oracle, monkeypatch):
     assert shard_ms < 0.97 * full_ms, (shard_ms, full_ms)
 
 
-def test_properties_at_scale(gen):
-    """cfg3 (1e5 individuals / 1e4 probands / 20 generations): too slow for the oracle in a
-    unit test, so check size-independent properties: symmetry, diagonal range, the default
-    kernel against the naive kernel bit for bit, and a checksum that is stable across runs."""
+def test_cfg3_full_size_bit_exact(gen, oracle, monkeypatch):
+    """cfg3 at full size (1e5 individuals / 1e4 probands / 20 generations) against the oracle (C/OpenMP: a
+    few seconds), bit for bit: the default kernels (FULL levels), the same pedigree with every level forced
+    through the SPLIT kernels (certified-rows kernel, then the grouping-exact one), the naive kernel, and
+    the size-independent properties (symmetry, diagonal range)."""
     from genlib_jl_amd import synth
     ind, fa, mo, sex, pro = synth.random_mating(100_000, 10_000, 20)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
     ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
     pl = gen.plan(ped, pro)
+    assert set(pl.step_modes()) == {0}
     a = pl.compute(kernel=0)
     b = pl.compute(kernel=1)
     pl.close()
-    _assert_equal(a, b)
+    _assert_equal(a, want)
+    _assert_equal(b, want)
     assert np.array_equal(a, a.T)
     d = a.diagonal()
     assert d.min() >= 0.5 and d.max() < 1.0
     assert a.min() >= 0.0 and (a - np.diag(d)).max() <= 0.5
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")
+    for env in ({}, {"GENPHI_NO_FAST": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, pro)
+        assert set(pl.step_modes()) == {1}
+        _assert_equal(pl.compute(), want)
+        pl.close()
+    for k in ("GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_FAST"):
+        monkeypatch.delenv(k, raising=False)
 
 
 def test_phi_mean_on_device(gen, oracle):
