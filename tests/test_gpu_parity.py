@@ -298,6 +298,23 @@ def test_cfg3_full_size_bit_exact(gen, oracle, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
+def test_cfg4_shaped_mid_size_bit_exact(gen, oracle):
+    """The headline configuration's kernel geometry at a size the oracle still does in about a minute: 1.6e5
+    individuals / 2.9e4 probands / 6 generations -- cuts of ~20k members (SPLIT by default: the 1024-thread
+    certified-rows kernel, 80 KB source rows) and a final level of 2.9e4 columns (512-thread kernel, two column
+    chunks per row), default settings, no test hooks.  Full matrix and two row shards, bit for bit."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(160_000, 29_000, 6)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    assert set(pl.step_modes()) == {1} and len(want) == 29_000
+    _assert_equal(pl.compute(), want)
+    parts = [pl.compute(rows=r) for r in [(0, 9_000), (9_000, 29_000)]]
+    _assert_equal(np.concatenate(parts, axis=0), want)
+    pl.close()
+
+
 def test_phi_mean_on_device(gen, oracle):
     """phiMean reduced on the device (no 40 GB device-to-host copy)."""
     ped = gen.genealogy(gen.geneaJi)
