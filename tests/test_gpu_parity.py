@@ -315,6 +315,25 @@ def test_cfg4_shaped_mid_size_bit_exact(gen, oracle):
     pl.close()
 
 
+def test_wide_cuts_at_real_size_default_settings(gen, oracle):
+    """WIDE levels without any test hook: overlapping generations (40 % of the parents from g-2) make cuts of
+    39.6k, 48.0k and 37.0k members, wider than the 36 864 floats of LDS a source row may take.  The plan holds a
+    WIDE step whose new x new block is a SPLIT sub-step written in place, one whose parents are too many for
+    that (per-entry kernel on the block), and a WIDE last step (proband-order delivery); bit for bit against
+    the oracle (about a minute of CPU), plus a row shard."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(150_000, 30_000, 5, skip_permille=400)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    modes = pl.step_modes()
+    assert modes == [1, 2, 2, 2] and max(pl.levels()[0]) > 36_864
+    assert {pl.step_info(k)[3] for k in range(1, 4)} == {1, 3}           # SPLIT sub-step and per-entry fallback
+    _assert_equal(pl.compute(), want)
+    _assert_equal(pl.compute(rows=(5_000, 5_700)), want[5_000:5_700])
+    pl.close()
+
+
 def test_phi_mean_on_device(gen, oracle):
     """phiMean reduced on the device (no 40 GB device-to-host copy)."""
     ped = gen.genealogy(gen.geneaJi)
