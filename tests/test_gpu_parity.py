@@ -521,6 +521,30 @@ def test_full_size_cfg4_properties(gen):
     pl.close()
 
 
+def test_full_size_cfg4o_properties(gen):
+    """The overlapping-generations workload of the bench at full size (1e6 individuals / 1e5 probands, 0.5 % of the
+    parents from g-2: cuts to 123.5k members, 23 WIDE levels, both routes for the dragged blocks, source
+    positions beyond 16 bits): the Float64 row-sum checksums of the block-assembly kernels and of the
+    one-thread-per-entry kernel are bit-identical, and sampled row blocks are bit-symmetric."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(1_000_000, 100_000, 30, skip_permille=5)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    n = pl.n_probands
+    modes = pl.step_modes()
+    assert n == 100_000 and modes.count(2) == 23 and max(pl.levels()[0]) > 120_000
+    pl.compute_device()
+    full = pl.result_sums()
+    pl.compute_device(kernel=1)
+    assert pl.result_sums() == full                                # per-entry kernel: identical checksums
+    a = pl.compute(rows=(2000, 2064))
+    b = pl.compute(rows=(91_000, 91_064))
+    assert np.array_equal(a[:, 91_000:91_064], b[:, 2000:2064].T)  # bit-symmetric
+    d = np.concatenate([a[np.arange(64), 2000 + np.arange(64)], b[np.arange(64), 91_000 + np.arange(64)]])
+    assert d.min() >= 0.5 and d.max() < 1.0 and a.min() >= 0.0 and a.max() < 1.0
+    pl.close()
+
+
 def _merge(peds):
     """Disjoint union of (ind, father, mother, sex, pro) pedigrees, IDs relabelled."""
     ind, fa, mo, sex, pro, off = [], [], [], [], [], 0
