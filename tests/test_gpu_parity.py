@@ -334,6 +334,30 @@ def test_wide_cuts_at_real_size_default_settings(gen, oracle):
     pl.close()
 
 
+def test_many_probands_from_few_parents(gen, oracle, monkeypatch):
+    """A final level much wider than the cut above it (1100 parents, 20 000 probands: 18 children per
+    parent): the FULL kernel walks 20 000 columns per row from two 4.4 KB source rows; the same pedigree
+    through the SPLIT kernels (5 column chunks at the forced 4 columns per thread); row shards."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(22_200, 20_000, 3)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    assert pl.step_modes() == [0, 0] and pl.levels()[0][-2] < 1200
+    _assert_equal(pl.compute(), want)
+    _assert_equal(pl.compute(rows=(123, 4567)), want[123:4567])
+    pl.close()
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")
+    monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+    monkeypatch.setenv("GENPHI_MAX_CPT", "4")
+    pl = gen.plan(ped, pro)
+    assert pl.step_modes() == [1, 1]
+    _assert_equal(pl.compute(), want)
+    pl.close()
+    for k in ("GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_SMALL", "GENPHI_MAX_CPT"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_phi_mean_on_device(gen, oracle):
     """phiMean reduced on the device (no 40 GB device-to-host copy)."""
     ped = gen.genealogy(gen.geneaJi)
