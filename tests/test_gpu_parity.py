@@ -358,6 +358,31 @@ def test_many_probands_from_few_parents(gen, oracle, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
+def test_huge_sibships_through_the_split_kernels(gen, oracle, monkeypatch):
+    """Three sires per generation of 600 (sibships of ~200 by one father: sibling groups are cut every 8
+    rows, consecutive groups share their A row), heavy inbreeding (most stores inexact), every level forced
+    through the SPLIT kernels: certified-rows kernel where the rows qualify, grouping-exact kernel for the
+    rest and, hook, for everything."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.deep_inbred(25, 600, 3)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")
+    monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+    for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_MAX_GROUP": "3"}, {"GENPHI_FAST_NT": "512", "GENPHI_CERT_MIN_EXP": "-2"}):
+        for k in ("GENPHI_NO_FAST", "GENPHI_MAX_GROUP", "GENPHI_FAST_NT", "GENPHI_CERT_MIN_EXP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, pro)
+        assert set(pl.step_modes()) == {1}
+        _assert_equal(pl.compute(), want)
+        _assert_equal(pl.compute(rows=(7, 311)), want[7:311])
+        pl.close()
+    for k in ("GENPHI_NO_FAST", "GENPHI_MAX_GROUP", "GENPHI_FAST_NT", "GENPHI_CERT_MIN_EXP", "GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_SMALL"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_phi_mean_on_device(gen, oracle):
     """phiMean reduced on the device (no 40 GB device-to-host copy)."""
     ped = gen.genealogy(gen.geneaJi)
