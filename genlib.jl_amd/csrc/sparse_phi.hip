@@ -14,13 +14,16 @@
 // "fix" it).
 //
 // Design here (not a translation): the queue order is depth-sorted (a child is enqueued while its
-// deepest parent is processed), so all individuals of one depth -- a WAVE -- only need kinships
-// with strictly older individuals and with each other through those:
+// deepest parent is processed) WHATEVER the ranks are (with genealogy(...; sort=false) the rank is the
+// file position and need not follow the depth), so all individuals of one depth -- a WAVE -- only
+// need kinships with strictly older individuals and with each other through those:
 //   T[i][q]  = RN32(L(f_i, q)/2 + L(m_i, q)/2)      new i x every live older q   (one kernel)
-//   S[i][j]  = RN32(T[j][f_i]/2 + T[j][m_i]/2)      new i x new j, j processed before i
+//   S[i][j]  = RN32(L'(j, f_i)/2 + L'(j, m_i)/2)    new i x new j, j processed before i, where
+//              L'(j, p) = T[j][p] if rank(p) < rank(j) (p left the queue before j), else 0
 //   S[i][i]  = RN32(1/2 + L(f_i, m_i)/2)
 // with L(a, b) = the stored value if the (earlier, later) key equals the (smaller rank, larger rank)
-// key, else 0.  The live set is a dense matrix in HBM ("active matrix"), compacted after every wave
+// key, else 0 (src/compute.jl:366-390 looks up phi[min rank][max rank], :392-394 stores under
+// [rank of the live one][rank of the new one]).  The live set is a dense matrix in HBM ("active matrix"), compacted after every wave
 // (retired parents leave), exactly like the cuts of the dense path with other membership rules.
 // The host simulates the queue once (integers only) to get the processing order, the waves and the
 // wave after which every individual retires; all kinship arithmetic runs in the kernels below.
@@ -46,13 +49,13 @@ __device__ __forceinline__ float half32(float v) { return v / 2.0f; }
 
 // stored value of the pair of active slots (a, b), as a lookup sees it (see L above); M is the
 // active matrix (pitch ld), meta[s] = (rank, processing index) of slot s; none = zero row / column
+// meta = (rank, processing index): does a lookup find the kinship of two distinct individuals?
+__device__ __forceinline__ bool key_found(int2 ma, int2 mb) { return (ma.y < mb.y) == (ma.x < mb.x); }
+
 __device__ __forceinline__ float lookup(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int a, int b, int none)
 {
     if (a == none || b == none) return 0.f;
-    if (a != b) {
-        const int2 ma = meta[a], mb = meta[b];
-        if ((ma.y < mb.y) != (ma.x < mb.x)) return 0.f;        // stored under a key no lookup uses
-    }
+    if (a != b && !key_found(meta[a], meta[b])) return 0.f;     // stored under a key no lookup uses
     return M[(long long)a * ld + b];
 }
 
@@ -79,7 +82,8 @@ sparse_new_old_kernel(const float *__restrict__ M, long long ld, const int2 *__r
 __global__ void __launch_bounds__(256)
 sparse_assemble_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old,
                        const int2 *__restrict__ par, const float *__restrict__ T, long long ldT,
-                       const int *__restrict__ keep, int n_surv, int n_new, float *__restrict__ out, long long ld_out)
+                       const int *__restrict__ keep, int n_surv, int n_new, const int2 *__restrict__ meta_next,
+                       float *__restrict__ out, long long ld_out)
 {
     const int r = blockIdx.x;                                    // 0 .. n_surv + n_new (the last one is the zero row)
     const int n_next = n_surv + n_new;
@@ -102,8 +106,12 @@ sparse_assemble_kernel(const float *__restrict__ M, long long ld, const int2 *__
                 } else {
                     const int i = max(a, b), j = min(a, b);      // j left the queue before i
                     const int2 p = par[i];
-                    const float tf = p.x == n_old ? 0.f : T[(long long)j * ldT + p.x];
-                    const float tm = p.y == n_old ? 0.f : T[(long long)j * ldT + p.y];
+                    // the parents left the queue before j (an earlier wave): T[j][parent] sits under the key
+                    // (rank parent, rank j), which the lookup (smaller rank, larger rank) finds only when
+                    // rank parent < rank j -- always true for depth-sorted ranks, not with sort = false
+                    const int2 mj = meta_next[n_surv + j];
+                    const float tf = (p.x == n_old || !key_found(meta[p.x], mj)) ? 0.f : T[(long long)j * ldT + p.x];
+                    const float tm = (p.y == n_old || !key_found(meta[p.y], mj)) ? 0.f : T[(long long)j * ldT + p.y];
                     v = static_cast<float>(0.0 + static_cast<double>(half32(tf)) + static_cast<double>(half32(tm)));
                 }
             }
@@ -229,6 +237,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     std::vector<Wave> waves;
     std::vector<int> active;                                     // pruned indices, slot order
     std::vector<int> slot_of(m, -1);
+    std::vector<int> live_pro_ranks;                             // pruned indices (= rank - 1) of the probands processed so far, ascending
     size_t max_mat = 64, max_T = 64, max_meta = 1, max_par = 1, n_stale = 0;
     for (int b = 0; b < m;) {
         int e = b;
@@ -247,15 +256,19 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         w.n_surv = static_cast<int>(next.size());
         for (int k = b; k < e; ++k) next.push_back(order[k]);
         for (size_t s = 0; s < next.size(); ++s) { slot_of[next[s]] = static_cast<int>(s); w.meta_next.push_back(make_int2(next[s] + 1, proc[next[s]])); }
-        // entries (j proband, x non-proband) of this wave with proc(j) < proc(x) and rank(x) < rank(j):
-        // x's retirement does not delete them from j's dictionary (src/compute.jl:408-410 tests rank_j < rank_x)
-        for (int kj = b; kj < e; ++kj) {
-            const int j = order[kj];
-            if (!pro_flag[j]) continue;
-            for (int kx = kj + 1; kx < e; ++kx) {
-                const int x = order[kx];
-                if (!pro_flag[x] && x < j) w.stale.push_back(make_int2(slot_of[j], slot_of[x]));
-            }
+        // Entries that outlive their column (src/compute.jl:401-430): when a non-proband x retires, phi[rank j][rank x]
+        // is deleted only for live j with rank j < rank x.  The entry exists when j left the queue before x, so every
+        // proband j with proc(j) < proc(x) and rank(j) > rank(x) keeps it for good (`show` counts it, phiMean sums it) --
+        // j of an earlier wave included (only possible when ranks are not depth-sorted: sort = false).  Gathered right
+        // after the wave that processes x, while x's row is in the active matrix.  live_pro_ranks: ranks of the probands
+        // processed so far, ascending.
+        for (int kx = b; kx < e; ++kx) {
+            const int x = order[kx];
+            if (pro_flag[x]) { live_pro_ranks.insert(std::upper_bound(live_pro_ranks.begin(), live_pro_ranks.end(), x), x); continue; }
+            for (auto it = std::upper_bound(live_pro_ranks.begin(), live_pro_ranks.end(), x); it != live_pro_ranks.end(); ++it)
+                w.stale.push_back(make_int2(slot_of[*it], slot_of[x]));
+            if (n_stale + w.stale.size() > (size_t(1) << 28))
+                return bail(GENPHI_ERR_ALLOC, "genphi_sparse_phi: more than 2^28 entries outlive their column (ranks far from depth order)");
         }
         n_stale += w.stale.size();
         max_mat = std::max(max_mat, static_cast<size_t>((next.size() + 1) * pitch_of(static_cast<long long>(next.size()))));
@@ -312,7 +325,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         {
             dim3 grid(static_cast<unsigned>(n_next + 1), static_cast<unsigned>(std::min<long long>((ld_next + 255) / 256, 64)));
             hipLaunchKernelGGL(sparse_assemble_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta[cur], w.n_old, d_par, dT, ldT,
-                               d_keep, w.n_surv, w.n_new, dM[cur ^ 1], ld_next);
+                               d_keep, w.n_surv, w.n_new, d_meta[cur ^ 1], dM[cur ^ 1], ld_next);
             SP_GO(hipGetLastError());
         }
         if (!w.stale.empty()) {

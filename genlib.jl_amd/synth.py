@@ -117,6 +117,37 @@ def chain_two_lines(depth):
     return a(ind), a(father), a(mother), a(sex), a(tips)
 
 
+def parents_first_shuffle(ind, father, mother, sex, seed=1):
+    """A random file order in which every parent still precedes its children but the depths are
+    interleaved (what a hand-maintained pedigree file looks like): the input of
+    gen.genealogy(...; sort=false), where the rank is the file position (src/create.jl:131,161,
+    :234-254) and need not follow the ancestral depth.  Visits the individuals in a random order and
+    places each one right after its not-yet-placed ancestors."""
+    ind = np.asarray(ind, dtype=np.int64)
+    n = len(ind)
+    pos = {int(i): k for k, i in enumerate(ind)}
+    fa = [pos[int(x)] if x else -1 for x in father]
+    mo = [pos[int(x)] if x else -1 for x in mother]
+    placed = np.zeros(n, dtype=bool)
+    out = []
+    for start in np.random.default_rng(seed).permutation(n):
+        stack = [int(start)]
+        while stack:
+            x = stack[-1]
+            if placed[x]:
+                stack.pop()
+                continue
+            todo = [q for q in (fa[x], mo[x]) if q >= 0 and not placed[q]]
+            if todo:
+                stack.extend(todo)
+            else:
+                placed[x] = True
+                out.append(x)
+                stack.pop()
+    o = np.asarray(out, dtype=np.int64)
+    return ind[o], np.asarray(father, dtype=np.int64)[o], np.asarray(mother, dtype=np.int64)[o], np.asarray(sex, dtype=np.int64)[o]
+
+
 def write_tsv(path, ind, father, mother, sex):
     """Reference on-disk format (data/geneaJi.csv): tab-separated, header row."""
     with open(path, "w") as fh:

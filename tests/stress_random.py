@@ -2,7 +2,7 @@
     python tests/stress_random.py [seconds] [seed]
 Random pedigrees x kernel families (LDS budget forces FULL / SPLIT / WIDE) x certificate thresholds
 (mixed fast / grouping-exact SPLIT levels) x workgroup variants x proband subsets x row shards x the
-Float64 sweep x sparse_phi, every result compared with the oracle bit for bit.  Prints one line per
+Float64 sweep x sparse_phi x genealogy(sort = true | false), every result compared with the oracle bit for bit.  Prints one line per
 failure with everything needed to reproduce it, and a summary."""
 import os
 import sys
@@ -60,8 +60,12 @@ def main():
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
-        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
-        oped = O.Pedigree(ind, fa, mo)
+        sort = bool(r.random() < 0.5)                                         # sort=false: the file order is the rank
+        if not sort:
+            ind, fa, mo, sex = synth.parents_first_shuffle(ind, fa, mo, sex, seed=case & 0xffff)
+        env["sort"] = str(sort)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex}, sort=sort)
+        oped = O.Pedigree(ind, fa, mo, sort=sort)
         want = oped.phi(pro)
         n = len(want)
         what = []
@@ -87,7 +91,9 @@ def main():
                 K = gen.sparse_phi(ped, sub)
                 Ko = O.SparsePhi(oped, sub)
                 got = K.get(np.repeat(sub, len(sub)), np.tile(sub, len(sub))).reshape(len(sub), len(sub)).astype(np.float32)
-                if not np.array_equal(got, Ko.matrix()) or repr(K) != Ko.show():
+                ge, we = K.entries(), Ko.entries()
+                same_entries = sorted(zip(ge[0].tolist(), ge[1].tolist(), ge[2].tolist())) == sorted(zip(we[0].tolist(), we[1].tolist(), we[2].tolist()))
+                if not np.array_equal(got, Ko.matrix()) or repr(K) != Ko.show() or not same_entries or gen.phiMean(K) != Ko.phi_mean():
                     what.append("sparse")
         except Exception as e:          # noqa: BLE001
             what.append(f"exception {type(e).__name__}: {e}")

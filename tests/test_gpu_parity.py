@@ -800,9 +800,13 @@ def test_branching_then_phi(gen, oracle):
     pro = gen.pro(ped)[10:60]
     pruned = gen.branching(ped, pro=pro)
     assert len(pruned) < len(ped)
-    _assert_equal(gen.phi(pruned, pro), gen.phi(ped, pro))
+    want = oracle.Pedigree.from_file(gen.genea140).phi(pro)
+    _assert_equal(gen.phi(pruned, pro), want)
+    _assert_equal(gen.phi(ped, pro), want)
     ped = gen.genealogy(gen.geneaJi)
-    _assert_equal(gen.phi(gen.branching(ped, pro=[1, 29]), [1, 29]), gen.phi(ped, [1, 29]))
+    wantj = oracle.Pedigree.from_file(gen.geneaJi).phi([1, 29])
+    _assert_equal(gen.phi(gen.branching(ped, pro=[1, 29]), [1, 29]), wantj)
+    _assert_equal(gen.phi(ped, [1, 29]), wantj)
 
 
 def _sparse_check(gen, oracle, ind, fa, mo, sex, pro, sort=True):
@@ -865,6 +869,95 @@ def test_sparse_phi_kinship_matrix(gen, oracle):
     g = oracle.read_tsv(gen.genea140)
     ped = gen.genealogy(gen.genea140)
     _sparse_check(gen, oracle, *g, pro=gen.pro(ped)[:25])
+
+
+def test_sparse_phi_unsorted_ranks(gen, oracle):
+    """gen.genealogy(...; sort=false) (src/create.jl:131,161): the rank is the file position, so an
+    individual of an earlier depth can carry the larger rank.  sparse_phi then (i) finds fewer kinships
+    (lookups use (smaller rank, larger rank), stores use (earlier, later): src/compute.jl:366-394) and
+    (ii) keeps entries of retired columns in the dictionaries of probands of EARLIER depths
+    (:401-430 deletes phi[rank_j][parent] only for rank_j < parent rank).  Every getindex, the `show`
+    line, phiMean and the stored entries must equal the literal restatement."""
+    from genlib_jl_amd import synth
+    # file order P1 P2 S=(P1,P2) F3 x=(S,F3) j=(P1,P2) F4 y=(x,F4); probands j, y.  j leaves the queue in the
+    # depth-2 wave, x in the depth-3 wave, rank(x) = 5 < rank(j) = 6: (6, 5) = 0.125 outlives x
+    ind = np.arange(1, 9)
+    fa = np.array([0, 0, 1, 0, 3, 1, 0, 5]); mo = np.array([0, 0, 2, 0, 4, 2, 0, 7]); sex = np.array([1, 2, 1, 2, 1, 2, 2, 1])
+    K, want = _sparse_check(gen, oracle, ind, fa, mo, sex, [6, 8], sort=False)
+    assert repr(K) == "2×2 KinshipMatrix with 3 stored entries." and float(gen.phiMean(K)) == 0.125
+    assert want.show() == repr(K) and float(want.phi_mean()) == 0.125
+    K, _ = _sparse_check(gen, oracle, ind, fa, mo, sex, [6, 8], sort=True)  # depth-sorted ranks: (6, 7) is deleted, Phi(j, y) is found
+    assert K[6, 8] == 0.0625 and float(gen.phiMean(K)) == 0.0625
+    n_cross = 0
+    for args, kw, seed in [((600, 60, 6), dict(skip_permille=100), 1), ((2000, 150, 8), dict(skip_permille=0), 2),
+                           ((1500, 100, 12), dict(skip_permille=200, seed=9), 3), ((900, 80, 7), dict(skip_permille=50, seed=3), 4)]:
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        if seed == 4:
+            mo = mo.copy(); mo[::13] = 0                                    # one-parent individuals
+        i2, f2, m2, s2 = synth.parents_first_shuffle(ind, fa, mo, sex, seed=seed)
+        extra = i2[np.random.default_rng(seed).integers(0, len(i2), 12)]    # ancestors among the probands: earlier depths, any rank
+        for p in (pro, np.concatenate([pro[::2], extra])):
+            K, want = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=False)
+            a, b = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=True)
+            n_cross += K.info()[1] != a.info()[1]
+    assert n_cross >= 3                                                     # the file order really changes what is stored
+    g = oracle.read_tsv(gen.genea140)                                       # genea140 in its own file order (not depth-sorted)
+    ped = gen.genealogy(gen.genea140, sort=False)
+    assert not np.array_equal(ped.ind, gen.genealogy(gen.genea140).ind)
+    _sparse_check(gen, oracle, *g, pro=gen.pro(ped)[:25], sort=False)
+
+
+def test_dense_phi_f_and_pairs_with_unsorted_ranks(gen, oracle, monkeypatch):
+    """The same for the dense path: with sort=false the rank (file position) decides which side the
+    per-pair kernel climbs first (src/compute.jl:130,139), i.e. the grouping of the Float64 sums.  Every
+    kernel family (FULL, SPLIT certified / grouping-exact / mixed, WIDE both routes, SMALL, per-entry,
+    identity), row shards, gen.f and the pairwise gen.phi on parents-first files with interleaved depths,
+    against the oracle run on the same order."""
+    from genlib_jl_amd import synth
+    from genlib_jl_amd import _capi
+    base = synth.random_mating(5000, 500, 8, skip_permille=60)
+    tiny = synth.chain_two_lines(22); tiny2 = synth.chain_two_lines(40)    # kinships 2^-45, 2^-81: rows without a certificate
+    knobs = ("GENPHI_FULL_MAX_FLOATS", "GENPHI_LDS_CAP_FLOATS", "GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_WIDE_ROUTE",
+             "GENPHI_NO_SMALL", "GENPHI_FAST_NT", "GENPHI_MAX_CPT")
+    for case, seed in [(_merge([base, tiny, tiny2]), 1), (synth.random_mating(3000, 300, 12, skip_permille=150, seed=11), 2),
+                       (synth.deep_inbred(40, 30, 3), 3)]:
+        ind, fa, mo, sex, pro = case
+        i2, f2, m2, s2 = synth.parents_first_shuffle(ind, fa, mo, sex, seed=seed)
+        if seed == 2:
+            m2 = m2.copy(); m2[::17] = 0                                    # one-parent members
+        ped = gen.genealogy({"ind": i2, "father": f2, "mother": m2, "sex": s2}, sort=False)
+        assert np.array_equal(ped.ind, i2)                                  # the file order IS the rank order
+        oped = oracle.Pedigree(i2, f2, m2, sort=False)
+        pro = np.concatenate([np.random.default_rng(seed).permutation(pro), i2[:3]])
+        want = oped.phi(pro)
+        n = len(want)
+        for env in ({}, {"GENPHI_NO_SMALL": "1"}, {"GENPHI_FULL_MAX_FLOATS": "0"}, {"GENPHI_FULL_MAX_FLOATS": "0", "GENPHI_NO_FAST": "1"},
+                    {"GENPHI_FULL_MAX_FLOATS": "0", "GENPHI_CERT_MIN_EXP": "-6", "GENPHI_LDS_CAP_FLOATS": "1024"},
+                    {"GENPHI_FULL_MAX_FLOATS": "0", "GENPHI_FAST_NT": "512", "GENPHI_MAX_CPT": "4", "GENPHI_CERT_MIN_EXP": "-3"},
+                    {"GENPHI_LDS_CAP_FLOATS": "300", "GENPHI_WIDE_ROUTE": "A"}, {"GENPHI_LDS_CAP_FLOATS": "300", "GENPHI_WIDE_ROUTE": "B", "GENPHI_NO_FAST": "1"},
+                    {"GENPHI_LDS_CAP_FLOATS": "150", "GENPHI_FULL_MAX_FLOATS": "0", "GENPHI_CERT_MIN_EXP": "-8"}):
+            for k in knobs:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pl = gen.plan(ped, pro)
+            _assert_equal(pl.compute(), want)
+            _assert_equal(np.concatenate([pl.compute(rows=r) for r in [(0, 5), (5, n // 2), (n // 2, n)]], axis=0), want)
+            pl.close()
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        _assert_equal(gen.phi(ped, pro, kernel=1), want)
+        if seed != 3:                                                       # (the pairwise recursion is exponential on the inbred lines)
+            ids = np.random.default_rng(seed).choice(i2, 40, replace=False)
+            assert np.array_equal(gen.f(ped, ids), oped.f(ids))
+            a = np.random.default_rng(seed + 7).choice(i2, 16); b = np.random.default_rng(seed + 8).choice(i2, 16)
+            got = _capi.phi_pairs(ped.ind, ped.father, ped.mother, a, b)
+            assert np.array_equal(got, np.array([oped.phi_pair(int(x), int(y)) for x, y in zip(a, b)]))
+    # genea140 in file order
+    ped = gen.genealogy(gen.genea140, sort=False)
+    g = oracle.read_tsv(gen.genea140)
+    oped = oracle.Pedigree(g[0], g[1], g[2], sort=False)
+    _assert_equal(gen.phi(ped), oped.phi())
 
 
 def test_cfg4o_downscaled_twin(gen, oracle, monkeypatch):

@@ -104,3 +104,43 @@ def test_sparse_phi_oracle_reproduces_the_reference_pins(oracle):
     assert np.array_equal(K.matrix(), ped.phi())
     with pytest.raises(KeyError):
         K[(1, 17)]                                       # 17 is not a proband
+
+
+def test_sparse_phi_oracle_with_unsorted_ranks(oracle):
+    """genealogy(...; sort=false) keeps the file order as the rank (src/create.jl:131,161).  File order
+    P1 P2 S=(P1,P2) F3 x=(S,F3) j=(P1,P2) F4 y=(x,F4), probands [j, y]: j leaves the queue with the depth-2
+    wave, x with the depth-3 wave, and rank(x) = 5 < rank(j) = 6, so x's retirement (src/compute.jl:401-430,
+    `if rank_j < parent_rank`) leaves phi[6][5] = 0.125 in j's dictionary: `show` counts 3 entries and
+    phiMean is 0.125 -- while the lookup of (j, x) under (5, 6) finds nothing, so Phi(j, y) reads 0.  With sort=true
+    the ranks are depth-sorted (j = 6, x = 7): the entry is deleted and Phi(j, y) = 0.0625 is found and stored."""
+    ind = [1, 2, 3, 4, 5, 6, 7, 8]
+    fa = [0, 0, 1, 0, 3, 1, 0, 5]
+    mo = [0, 0, 2, 0, 4, 2, 0, 7]
+    K = oracle.SparsePhi(oracle.Pedigree(ind, fa, mo, sort=False), [6, 8])
+    assert K.show() == "2×2 KinshipMatrix with 3 stored entries."
+    assert float(K.phi_mean()) == 0.125
+    r, c, v = K.entries()
+    assert sorted(zip(r.tolist(), c.tolist(), v.tolist())) == [(6, 5, 0.125), (6, 6, 0.5), (8, 8, 0.5)]
+    K = oracle.SparsePhi(oracle.Pedigree(ind, fa, mo, sort=True), [6, 8])
+    assert K.show() == "2×2 KinshipMatrix with 3 stored entries." and float(K.phi_mean()) == 0.0625
+    r, c, v = K.entries()
+    assert sorted(zip(r.tolist(), c.tolist(), v.tolist())) == [(6, 6, 0.5), (6, 8, 0.0625), (8, 8, 0.5)]
+
+
+def test_parents_first_shuffle_is_a_valid_unsorted_file(oracle):
+    """tests' generator of sort=false inputs: parents precede children, depths are interleaved, and the
+    dense matrix does not depend on the file order (any parents-first order is a valid rank)."""
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(800, 60, 7, skip_permille=100)
+    i2, f2, m2, s2 = synth.parents_first_shuffle(ind, fa, mo, sex, seed=5)
+    assert sorted(i2.tolist()) == ind.tolist()
+    pos = {int(x): k for k, x in enumerate(i2)}
+    assert all(pos[int(p)] < k for k in range(len(i2)) for p in (f2[k], m2[k]) if p)
+    ped = gen.genealogy({"ind": i2, "father": f2, "mother": m2, "sex": s2}, sort=False)      # accepted as it is
+    assert np.array_equal(ped.ind, i2)
+    gen_of = np.searchsorted(np.cumsum([0] + [len(ind) // 7] * 7), i2, side="left")          # coarse generation of each row
+    assert np.any(np.diff(gen_of) < 0)                                                       # depths interleaved in file order
+    a = oracle.Pedigree(i2, f2, m2, sort=False).phi(pro)
+    b = oracle.Pedigree(ind, fa, mo).phi(pro)
+    assert np.array_equal(a, b)
