@@ -56,6 +56,18 @@ def measured_ceiling():
     return None, None
 
 
+def csrc_sha16():
+    """Fingerprint of genlib.jl_amd/csrc (same function as profiles/summarize.py): ties a committed
+    profiles/traffic_<workload>.json to the kernel sources it was collected with."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "genlib.jl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_workload(name):
     import genlib_jl_amd as gen
     from genlib_jl_amd import synth
@@ -247,7 +259,8 @@ def main():
         probe = gen.plan(ped, pro)
         cut_sizes = probe.levels()[0]
         probe.close()
-        fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0])
+        # the decision is collective (MIN over the ranks): every rank must take the same path
+        fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0], dist=dist, device=torch.device("cuda", local_rank))
         if args.exchange or os.environ.get("GENPHI_FORCE_EXCHANGE") == "1" or not fits:
             return run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits)
     t_plan = time.perf_counter()
@@ -349,11 +362,13 @@ def main():
             end_to_end["total_ms_plan_sweep_d2h"] = tot * 1e3
             end_to_end["pairs_per_s"] = n * n / tot
         ceiling, ceiling_src = measured_ceiling()
-        traffic = None
+        traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_stale = tj.get("csrc_sha16") != csrc_sha16()      # collected with other kernel sources than these
             except Exception:
                 traffic = None
         out = {
@@ -376,7 +391,9 @@ def main():
                          # accesses, 3 reads : 2 writes, no reuse) can move at all on this GPU, measured by
                          # profiles/microbench/row_stream.hip; and the rate of the REAL traffic when known
                          "measured_ceiling_GBs": ceiling, "measured_ceiling_source": ceiling_src,
-                         "traffic_source": f"profiles/traffic_{args.workload}.json (rocprofv3 PMC passes of this command; not re-collected by this run)" if traffic else None,
+                         "traffic_source": (f"profiles/traffic_{args.workload}.json (rocprofv3 PMC passes of this command; not re-collected by this run"
+                                            + ("; STALE: collected with other kernel sources than this run's" if traffic_stale else "; same kernel sources as this run") + ")") if traffic else None,
+                         "traffic_stale": traffic_stale,
                          "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),

@@ -29,7 +29,7 @@ _F32P = C.POINTER(C.c_float)
 
 class GenphiOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("kernel", C.c_int32), ("row_begin", C.c_int64),
-                ("row_end", C.c_int64), ("timing", C.c_int32), ("reserved", C.c_int32)]
+                ("row_end", C.c_int64), ("timing", C.c_int32), ("flags", C.c_int32)]
 
 
 class GenphiStats(C.Structure):
@@ -279,7 +279,7 @@ class PhiPlan:
         o.kernel = int(kernel)
         o.row_begin, o.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
         o.timing = 1 if timing else 0
-        o.reserved = (GENPHI_FLAG_STORAGE_F64 if storage64 else 0) | (GENPHI_FLAG_NO_GRAPH if no_graph else 0)
+        o.flags = (GENPHI_FLAG_STORAGE_F64 if storage64 else 0) | (GENPHI_FLAG_NO_GRAPH if no_graph else 0)
         return o
 
     def compute_device(self, device=None, kernel=0, rows=None, timing=False, storage64=False, no_graph=False):

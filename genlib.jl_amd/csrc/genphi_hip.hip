@@ -1367,6 +1367,64 @@ constexpr size_t kTailPadFloats = 64 * 1024;
 // pk / ord are padded so that the unrolled per-thread column loops need no clamp
 constexpr size_t kIdxPad = 32 * 1024;
 
+// Tuning, A/B and test hooks.  Every one is an environment variable that is read ONCE, when the plan is
+// created (genphi_plan_create), and kept in the plan: a plan never changes behaviour under the caller's
+// feet, and no launch path calls getenv.  The list (with what each is for) is in README.md,
+// "Environment hooks"; none is needed in production.
+struct Tuning {
+    int lds_cap_floats = 0;        // GENPHI_LDS_CAP_FLOATS   test: LDS budget for staged rows (forces SPLIT / WIDE on small inputs)
+    int full_max_floats = -1;      // GENPHI_FULL_MAX_FLOATS  tuning: FULL vs SPLIT threshold (row length in floats)
+    int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per sibling group of the SPLIT kernels
+    int full_bs = 0;               // GENPHI_FULL_BS          tuning: workgroup size of level_full_kernel
+    bool no_identity = false;      // GENPHI_NO_IDENTITY      test: level step 0 on a materialised 1/2 I
+    int cert_min_exp = -27;        // GENPHI_CERT_MIN_EXP     test: certificate threshold 2^e, e in [-27, 0] (always safe)
+    int dbg_step = -1;             // GENPHI_DBG_STEP         GENPHI_WG_TIMES builds: the step whose workgroup timing is recorded
+    bool no_fast = false;          // GENPHI_NO_FAST          test / A-B: grouping-exact SPLIT / FULL bodies only
+    int max_cpt = 0;               // GENPHI_MAX_CPT          test / tuning: columns per thread of a SPLIT chunk
+    int fast_nt = 0;               // GENPHI_FAST_NT          test / tuning: 512- or 1024-thread certified-rows kernel
+    char wide_route = 0;           // GENPHI_WIDE_ROUTE       A-B: 'A' / 'B' route of the WIDE levels (0 = by cost)
+    bool tt_noalign = false;       // GENPHI_TT_NOALIGN       A-B: transpose without line-aligned destination runs
+    bool no_shard_prune = false;   // GENPHI_NO_SHARD_PRUNE   test: a row shard computes every row of the upper levels
+    int shard_force_step = -1, shard_force_row = -1;   // GENPHI_SHARD_FORCE "step:row"  debugging aid
+    int shard_prune_min_step = 0;  // GENPHI_SHARD_PRUNE_MIN_STEP  debugging aid
+    bool no_small = false;         // GENPHI_NO_SMALL         test: no fused small-level runs
+    bool no_graph = false;         // GENPHI_NO_GRAPH         A-B: never replay a captured hipGraph
+    int d2h_threads = 0;           // GENPHI_D2H_THREADS      tuning: worker threads of genphi_result_to_host
+    bool d2h_pageable = false;     // GENPHI_D2H_PAGEABLE     A-B: no pinned staging ring
+    int fail_alloc_at = 0;         // GENPHI_TEST_FAIL_ALLOC  test: the k-th device allocation of an upload fails (error-path test)
+};
+
+static Tuning tuning_from_env()
+{
+    Tuning t;
+    auto geti = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    auto has = [](const char *name) { return std::getenv(name) != nullptr; };
+    t.lds_cap_floats = geti("GENPHI_LDS_CAP_FLOATS", 0);
+    t.full_max_floats = geti("GENPHI_FULL_MAX_FLOATS", -1);
+    t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
+    t.full_bs = geti("GENPHI_FULL_BS", 0);
+    t.no_identity = has("GENPHI_NO_IDENTITY");
+    t.cert_min_exp = geti("GENPHI_CERT_MIN_EXP", -27);
+    t.dbg_step = geti("GENPHI_DBG_STEP", -1);
+    t.no_fast = has("GENPHI_NO_FAST");
+    t.max_cpt = geti("GENPHI_MAX_CPT", 0);
+    t.fast_nt = geti("GENPHI_FAST_NT", 0);
+    if (const char *e = std::getenv("GENPHI_WIDE_ROUTE")) t.wide_route = (e[0] == 'B' || e[0] == 'b') ? 'B' : 'A';
+    t.tt_noalign = has("GENPHI_TT_NOALIGN");
+    t.no_shard_prune = has("GENPHI_NO_SHARD_PRUNE");
+    if (const char *e = std::getenv("GENPHI_SHARD_FORCE")) {
+        int fs = -1, fr = -1;
+        if (std::sscanf(e, "%d:%d", &fs, &fr) == 2) { t.shard_force_step = fs; t.shard_force_row = fr; }
+    }
+    t.shard_prune_min_step = geti("GENPHI_SHARD_PRUNE_MIN_STEP", 0);
+    t.no_small = has("GENPHI_NO_SMALL");
+    t.no_graph = has("GENPHI_NO_GRAPH");
+    t.d2h_threads = geti("GENPHI_D2H_THREADS", 0);
+    t.d2h_pageable = has("GENPHI_D2H_PAGEABLE");
+    t.fail_alloc_at = geti("GENPHI_TEST_FAIL_ALLOC", 0);
+    return t;
+}
+
 // Sibling groups of a SPLIT work list (rows sorted by (A source, B source); "no B" = n_prev sorts
 // last): runs of equal A source, capped.  Two nested lists over the same row descriptors:
 //   grp   : groups of <= 8 children, walked by level_split_fast_kernel (no per-child state)
@@ -1397,14 +1455,13 @@ struct DeviceStep {
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
-static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl)
+static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl, int max_group)
 {
     gl.desc.resize(n_rows);
     gl.grp.clear(); gl.grp_s.clear(); gl.span_s.clear();
     // groups are capped: a workgroup walks a group's children one after the other, so one huge
     // group (e.g. all parentless rows share "no A source") would be a serial tail
-    static const int env_group = std::getenv("GENPHI_MAX_GROUP") ? std::max(1, std::atoi(std::getenv("GENPHI_MAX_GROUP"))) : 8;
-    const int cap = env_group;
+    const int cap = max_group;
     const int cap_s = s.pos_ord ? cap : std::min(cap, 4);
     int lastA = -1;
     for (int w = 0; w < n_rows; ++w) {
@@ -1454,6 +1511,7 @@ static void put_groups(const GroupLists &gl, DeviceGroups &d, Put &&put)
 struct genphi_plan {
     Plan plan;
     genphi::PlanOptions popt;
+    Tuning tun;                                  // environment hooks, read once in genphi_plan_create
     // device state (created lazily by the first compute)
     bool on_device = false;
     int device = -1;
@@ -1477,6 +1535,8 @@ struct genphi_plan {
     // the stale graph can then never be replayed, and a fresh eager run precedes the next capture.
     long long graph_key[5] = {0, 0, 0, 0, 0}, eager_key[5] = {0, 0, 0, 0, 0};
     long long alloc_gen = 1;
+    bool level_bufs_ready = false;         // buf[] / psi_p exist (ensure_level_buffers)
+    int alloc_count = 0;                   // device allocations of uploads so far (GENPHI_TEST_FAIL_ALLOC)
     char *scratch = nullptr;               // genphi_result_sums / _entries staging (grown on demand)
     size_t scratch_bytes = 0;
     bool eager_valid = false;
@@ -1547,7 +1607,7 @@ static void free_device(genphi_plan *p)
     p->dsteps.clear(); p->sh_steps.clear();
     p->sh_valid = false;
     p->shard_cap = 0; p->shard_r0 = p->shard_r1 = -1;
-    p->buf_floats[0] = p->buf_floats[1] = 0;
+    p->buf_floats[0] = p->buf_floats[1] = 0; p->level_bufs_ready = false;
     p->result_floats = p->final_tmp_floats = 0; p->scratch_bytes = 0;
     p->res_ld = 0; p->res_row_begin = 0; p->res_n_rows = 0;
     for (void *q : p->pin) (void)hipHostFree(q);
@@ -1571,14 +1631,9 @@ int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
     *out = nullptr;
     genphi_plan *p = new (std::nothrow) genphi_plan();
     if (!p) return fail(GENPHI_ERR_ALLOC, "out of memory");
-    if (const char *env = std::getenv("GENPHI_LDS_CAP_FLOATS")) {   // test hook: force SPLIT / HALF mode on small inputs
-        const long v = std::atol(env);
-        if (v >= 16) p->popt.lds_cap_floats = static_cast<int32_t>(v);
-    }
-    if (const char *env = std::getenv("GENPHI_FULL_MAX_FLOATS")) {  // tuning hook: FULL vs SPLIT threshold
-        const long v = std::atol(env);
-        if (v >= 0) p->popt.full_max_floats = static_cast<int32_t>(v);
-    }
+    p->tun = tuning_from_env();
+    if (p->tun.lds_cap_floats >= 16) p->popt.lds_cap_floats = p->tun.lds_cap_floats;
+    if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
     std::string err;
     int rc;
     try {
@@ -1635,8 +1690,15 @@ void genphi_plan_destroy(genphi_plan *plan)
 
 }  // extern "C"
 
+// Device allocation of an upload; GENPHI_TEST_FAIL_ALLOC = k makes the k-th one of a plan fail (error-path test)
+static hipError_t plan_malloc(genphi_plan *p, void **ptr, size_t bytes)
+{
+    if (p->tun.fail_alloc_at > 0 && ++p->alloc_count == p->tun.fail_alloc_at) return hipErrorOutOfMemory;
+    return plan_malloc(p, ptr, bytes);
+}
+
 // upload the flat index arrays once
-static int upload_plan(genphi_plan *p, int device)
+static int upload_plan_impl(genphi_plan *p, int device)
 {
     if (p->on_device) {
         if (device >= 0 && device != p->device) free_device(p);
@@ -1649,7 +1711,7 @@ static int upload_plan(genphi_plan *p, int device)
     if (device >= ndev) return fail(GENPHI_ERR_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
     p->device = device;
-    p->on_device = true;
+    p->on_device = true;                              // (free_device releases whatever exists; upload_plan calls it on any failure below)
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     {
         hipDeviceProp_t prop;
@@ -1671,7 +1733,7 @@ static int upload_plan(genphi_plan *p, int device)
         const LevelStep &s = step_at(k);
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
         if (s.mode == genphi::kModeSplit) {
-            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k]);
+            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k], p->tun.max_group);
             total += groups_bytes(step_groups[k]);
         }
         if (s.mode == genphi::kModeWide)
@@ -1679,7 +1741,7 @@ static int upload_plan(genphi_plan *p, int device)
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->idx_blob), total));
+    HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t pad_bytes = 0) -> char * {
@@ -1736,7 +1798,7 @@ static int upload_plan(genphi_plan *p, int device)
 
     const size_t n_slots = n_all + 1;                    // queue / counter slots: one per (sub-)step
     p->n_slots = n_slots;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_queues), n_slots * 16 * sizeof(int)));
+    HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_queues), n_slots * 16 * sizeof(int)));
     {   // certificates: words [cert_off[c], cert_off[c] + n_c] belong to cut c (incl. its "none" row)
         p->cert_off.assign(pl.n_levels + 1, 0);
         size_t w = 0;
@@ -1746,26 +1808,34 @@ static int upload_plan(genphi_plan *p, int device)
         }
         p->cert_off[pl.n_levels] = w;
         p->cert_words = w;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cert), std::max<size_t>(w, 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gcnt), n_slots * 4 * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_glist), 2 * ((static_cast<size_t>(pl.max_cut) + 64) / 64 * 64) * sizeof(int)));
+        HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert), std::max<size_t>(w, 1) * sizeof(int)));
+        HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_gcnt), n_slots * 4 * sizeof(int)));
+        HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_glist), 2 * ((static_cast<size_t>(pl.max_cut) + 64) / 64 * 64) * sizeof(int)));
     }
     {
         std::vector<SmallStep> sm(pl.steps.size() + 1);
         for (size_t k = 0; k < pl.steps.size(); ++k)
             sm[k] = SmallStep{p->dsteps[k].srcA, p->dsteps[k].srcB, p->dsteps[k].ord,
                               static_cast<int>(pl.steps[k].n_prev), static_cast<int>(pl.steps[k].n)};
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_small), sm.size() * sizeof(SmallStep)));
+        HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_small), sm.size() * sizeof(SmallStep)));
         HIP_TRY(hipMemcpyAsync(p->d_small, sm.data(), sm.size() * sizeof(SmallStep), hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
+    return GENPHI_OK;
+}
+
+// The Float32 level matrices (ping-pong buffers, the compacted parent matrix of the WIDE steps): allocated by
+// the first Float32 sweep, not by the upload -- a Float64-storage sweep (gen.f, pairwise phi) never touches them.
+static int ensure_level_buffers_impl(genphi_plan *p)
+{
+    const Plan &pl = p->plan;
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
     for (int c = 0; c + 1 < pl.n_levels; ++c)
         need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]) + kTailPadFloats);
     for (int b = 0; b < 2; ++b) {
         if (need[b]) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float)));
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float)));
             // on the plan's own stream: hipMemset on the null stream is asynchronous to the host
             // and unordered with a non-blocking stream, so it could wipe level results later
             HIP_TRY(hipMemsetAsync(p->buf[b], 0, need[b] * sizeof(float), p->stream));
@@ -1780,13 +1850,39 @@ static int upload_plan(genphi_plan *p, int device)
             need_c = std::max(need_c, static_cast<size_t>(nn->n_prev) + 1);
         }
         if (need_p) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->psi_p, 0, need_p * sizeof(float), p->stream));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cert_p), need_c * sizeof(int)));
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_p), need_c * sizeof(int)));
             p->cert_p_words = need_c;
         }
     }
+    p->level_bufs_ready = true;
     return GENPHI_OK;
+}
+static int ensure_level_buffers(genphi_plan *p)
+{
+    if (p->level_bufs_ready) return GENPHI_OK;
+    const int rc = ensure_level_buffers_impl(p);
+    if (rc != GENPHI_OK) {                            // same rule as upload_plan: no half-allocated plan survives a failure
+        const std::string keep = g_last_error;
+        free_device(p);
+        g_last_error = keep;
+    }
+    return rc;
+}
+
+// A failed upload (out of memory is the expected failure of large plans) must not leave a plan that looks
+// uploaded: everything allocated so far is released, so that a retry uploads from scratch.
+static int upload_plan(genphi_plan *p, int device)
+{
+    const bool was = p->on_device && !(device >= 0 && device != p->device);
+    const int rc = upload_plan_impl(p, device);
+    if (rc != GENPHI_OK && !was) {
+        const std::string keep = g_last_error;
+        free_device(p);
+        g_last_error = keep;
+    }
+    return rc;
 }
 
 static int ensure_floats(genphi_plan *p, float **ptr, size_t *have, size_t need)
@@ -1907,10 +2003,10 @@ static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hi
     return hipErrorInvalidValue;
 }
 
-static int block_size_for(int64_t n)
+static int block_size_for(int64_t n, const Tuning &tun)
 {
-    if (const char *e = std::getenv("GENPHI_FULL_BS")) {         // tuning hook
-        const int v = std::atoi(e);
+    {
+        const int v = tun.full_bs;
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) return v;
     }
     if (n <= 512) return 64;
@@ -1920,7 +2016,7 @@ static int block_size_for(int64_t n)
 
 // level step 0 reads Psi_1 = 1/2 I: level_identity_kernel computes it from the indices alone
 // (GENPHI_NO_IDENTITY: test hook, the regular kernels on a materialised 1/2 I)
-static bool identity_source(int step) { return step == 0 && std::getenv("GENPHI_NO_IDENTITY") == nullptr; }
+static bool identity_source(int step, const Tuning &tun) { return step == 0 && !tun.no_identity; }
 
 // item / n_chunks as a multiply-high: exact for item < 2^32 / n_chunks (items are < 2^31 and n_chunks
 // is a handful); n_chunks == 1 has no 32-bit magic number and is flagged by 0
@@ -1932,10 +2028,9 @@ static unsigned chunk_magic_for(int n_chunks)
 // bits(2^-27) - 1: entries below 2^-27 (other than 0) void a row's exactness certificate.  Test hook:
 // GENPHI_CERT_MIN_EXP = e in [-27, 0] raises the bound to 2^e (always safe: fewer rows certified),
 // which makes mixed certified / uncertified levels out of ordinary small pedigrees.
-static unsigned cert_threshold()
+static unsigned cert_threshold(const Tuning &tun)
 {
-    const int min_exp = std::getenv("GENPHI_CERT_MIN_EXP") ? std::atoi(std::getenv("GENPHI_CERT_MIN_EXP")) : -27;
-    const int e = std::max(-27, std::min(0, min_exp));
+    const int e = std::max(-27, std::min(0, tun.cert_min_exp));
     return (static_cast<unsigned>(127 + e) << 23) - 1u;
 }
 
@@ -1957,10 +2052,9 @@ static LevelCtx main_ctx(genphi_plan *p, int step)
     c.s = &p->plan.steps[step]; c.d = &p->dsteps[step]; c.slot = step;
     c.cert_prev = p->d_cert + p->cert_off[step];
     c.cert_out = p->d_cert + p->cert_off[step + 1];      // (the last level's have no reader: harmless)
-    c.identity = identity_source(step);
+    c.identity = identity_source(step, p->tun);
     c.no_none_row = false;
-    const char *e = std::getenv("GENPHI_DBG_STEP");                            // default: the last step
-    c.dbg = (e ? std::atoi(e) : static_cast<int>(p->plan.steps.size()) - 1) == step;
+    c.dbg = (p->tun.dbg_step >= 0 ? p->tun.dbg_step : static_cast<int>(p->plan.steps.size()) - 1) == step;     // default: the last step
     return c;
 }
 
@@ -1981,7 +2075,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
     a.cert_prev = cx.cert_prev;
     a.cert_out = out_rows == nullptr ? cx.cert_out : nullptr;
     a.glist = nullptr; a.gcnt = nullptr; a.chunk_magic = 0;
-    a.cert_thresh = cert_threshold();
+    a.cert_thresh = cert_threshold(p->tun);
     if (n_rows <= 0) {
         // nothing to compute (a row shard whose ancestors do not reach this level), but the next level
         // still reads this level's all-zero "none" row for its parentless members
@@ -2000,7 +2094,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
     } else if (s.mode == genphi::kModeFull) {
         a.lds_row = lds_row;
         const size_t lds = 2 * static_cast<size_t>(lds_row) * sizeof(float);
-        const int bs = block_size_for(std::max(s.n, s.n_prev));
+        const int bs = block_size_for(std::max(s.n, s.n_prev), p->tun);
         if (s.pos_ord) {
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, true>), lds));
             hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows + a.zero_row), dim3(bs), lds, p->stream, a);
@@ -2014,7 +2108,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
         const int stg1k = (per_row4 + 1023) / 1024;
         // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
         const int stg_inst = stg1k <= 2 ? 2 : (stg1k <= 4 ? 4 : (stg1k <= 6 ? 6 : (stg1k <= 7 ? 7 : (stg1k <= 8 ? 8 : 9))));
-        const bool no_fast = std::getenv("GENPHI_NO_FAST") != nullptr;          // test / A-B hook: grouping-exact kernel only
+        const bool no_fast = p->tun.no_fast;                                    // test / A-B hook: grouping-exact kernel only
         const bool certs = !no_fast && kernel == 0;
         int *queue = p->d_queues + 16 * step;                                 // zeroed at the start of the sweep
         int *gcnt = p->d_gcnt + 4 * step;
@@ -2028,7 +2122,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
         int max_cpt;
         if (s.pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
         else           max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 8 ? 20 : 16);
-        const int env_cpt = std::getenv("GENPHI_MAX_CPT") ? std::atoi(std::getenv("GENPHI_MAX_CPT")) : 0;   // tuning hook: smaller chunks
+        const int env_cpt = p->tun.max_cpt;                                     // tuning hook: smaller chunks
         if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
@@ -2037,7 +2131,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
             // ---- certified groups: level_split_fast_kernel ----
             LevelArgs f = a;
             int f_nt = 1024, f_chunks = 1 << 30, f_stg = stg_inst;
-            const int force_nt = std::getenv("GENPHI_FAST_NT") ? std::atoi(std::getenv("GENPHI_FAST_NT")) : 0;          // test / tuning hook
+            const int force_nt = p->tun.fast_nt;                                // test / tuning hook
             for (int nt : {1024, 512}) {
                 if (force_nt && nt != force_nt) continue;
                 int stg = (per_row4 + nt - 1) / nt;
@@ -2105,7 +2199,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     const LevelCtx cx = main_ctx(p, step);
     const int n = static_cast<int>(s.n), nd = static_cast<int>(s.n_dragged), n_new = n - nd;
     const int none = static_cast<int>(s.n_prev);
-    const unsigned thr = cert_threshold();
+    const unsigned thr = cert_threshold(p->tun);
     int *cert_out = cx.cert_out;
     if (kernel == 1 || cx.identity) {
         // the per-entry kernel and the 1/2 I kernel take any cut width: all rows in one launch
@@ -2155,9 +2249,8 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     //   Per level of cfg4o (profiles/microbench/out/r02_ab_wide_route_per_level_cfg4o.out) B is faster from
     //   nd / n_prev ~ 0.67 downwards (the level at 0.29: 4.07 -> 3.52 ms), slower above (the widest level:
     //   24.9 -> 27.8 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 2/3.
-    const char *route_env = std::getenv("GENPHI_WIDE_ROUTE");            // (read per launch: the tests switch it between plans)
     bool route_b = !nn_naive && nd > 0 && n_new > 0 && s.nn[0].n_prev > 0;
-    if (route_b) route_b = route_env ? (route_env[0] == 'B' || route_env[0] == 'b') : (3LL * nd < 2LL * s.n_prev);
+    if (route_b) route_b = p->tun.wide_route ? p->tun.wide_route == 'B' : (3LL * nd < 2LL * s.n_prev);
     if (route_b) {
         // 3B. the dragged rows, all n columns
         const LevelStep &nn = s.nn[0];
@@ -2197,7 +2290,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         }
         // 4A. dragged x new = (new x dragged)^T
         if (n_new > 0 && nd > 0) {
-            static const bool tt_align = std::getenv("GENPHI_TT_NOALIGN") == nullptr;        // A/B hook
+            const bool tt_align = !p->tun.tt_noalign;                                        // A/B hook
             const int shift = tt_align ? (nd & 31) : 0;                     // destination runs start on 128-byte lines
             dim3 gt(static_cast<unsigned>((nd + kTT - 1) / kTT), static_cast<unsigned>((n_new + shift + kTT - 1) / kTT));
             hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(nd) * s.ld,
@@ -2306,11 +2399,13 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
 
     int rc = upload_plan(p, device);
     if (rc) return rc;
-    p->res_f64 = opts && (opts->reserved & GENPHI_FLAG_STORAGE_F64);
+    p->res_f64 = opts && (opts->flags & GENPHI_FLAG_STORAGE_F64);
     if (p->res_f64) {
         p->res_ld = pl.ld[L - 1];
         return compute_f64(p, r0, r1);
     }
+    rc = ensure_level_buffers(p);
+    if (rc) return rc;
     const int n_steps = L - 1;
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
@@ -2366,7 +2461,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         std::vector<char> gimg;
         if (n_steps > 0 && pl.steps[n_steps - 1].mode == genphi::kModeSplit) {
             GroupLists gl;
-            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl);
+            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl, p->tun.max_group);
             const size_t gb = groups_bytes(gl);
             if (gb > p->shard_blob_bytes) {
                 if (p->d_shard_blob) { HIP_TRY(hipFree(p->d_shard_blob)); p->d_shard_blob = nullptr; p->shard_blob_bytes = 0; }
@@ -2390,7 +2485,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         // upper levels restricted to the ancestors of the shard (walk the sources backwards)
         (void)hipFree(p->sh_blob); p->sh_blob = nullptr; p->sh_valid = false;
         p->sh_steps.assign(std::max(n_steps, 1), genphi_plan::ShardStep());
-        const bool sharded = n_rows < pl.n_pro && n_steps >= 2 && std::getenv("GENPHI_NO_SHARD_PRUNE") == nullptr;
+        const bool sharded = n_rows < pl.n_pro && n_steps >= 2 && !p->tun.no_shard_prune;
         if (sharded) {
             std::vector<std::vector<int>> host_rows(n_steps);
             std::vector<GroupLists> host_gl(n_steps);
@@ -2410,10 +2505,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 const LevelStep &sv = pl.steps[st];                                // produces cut st+1 (n = sv.n)
                 std::vector<char> need_prev(sv.n_prev + 1, 0);
                 std::vector<int> &rw = host_rows[st];
-                if (const char *e = std::getenv("GENPHI_SHARD_FORCE")) {            // debugging aid: "step:row"
-                    int fs = -1, fr = -1;
-                    if (std::sscanf(e, "%d:%d", &fs, &fr) == 2 && fs == st && fr >= 0 && fr < static_cast<int>(need.size())) need[fr] = 1;
-                }
+                if (p->tun.shard_force_step == st && p->tun.shard_force_row >= 0 && p->tun.shard_force_row < static_cast<int>(need.size()))
+                    need[p->tun.shard_force_row] = 1;                                  // debugging aid
                 if (sv.mode == genphi::kModeWide) {                                  // computes every row, reads every row
                     std::fill(need_prev.begin(), need_prev.end(), 1);
                     need.swap(need_prev);
@@ -2426,7 +2519,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         if (sv.srcB[i] < sv.n_prev) need_prev[sv.srcB[i]] = 1;
                     }
                 if (sv.mode == genphi::kModeSplit) {
-                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_gl[st]);
+                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_gl[st], p->tun.max_group);
                     total += groups_bytes(host_gl[st]);
                 }
                 total += al(rw.size() * sizeof(int));
@@ -2454,8 +2547,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
 
     // ---- the sweep: every launch of one gen.phi, in stream order ------------------------------
-    const int prune_min_step = std::getenv("GENPHI_SHARD_PRUNE_MIN_STEP") ? std::atoi(std::getenv("GENPHI_SHARD_PRUNE_MIN_STEP")) : 0;   // debugging aid
-    const bool small_off = std::getenv("GENPHI_NO_SMALL") != nullptr;            // test hook: per-level launches only
+    const int prune_min_step = p->tun.shard_prune_min_step;                     // debugging aid
+    const bool small_off = p->tun.no_small;                                      // test hook: per-level launches only
     std::vector<int> ev_after(std::max(n_steps, 1));                             // event recorded after step k (timing)
     for (int k = 0; k < static_cast<int>(ev_after.size()); ++k) ev_after[k] = k + 1;
     auto enqueue = [&]() -> int {
@@ -2474,7 +2567,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             // (materialised only for kernels that read it: level_identity_kernel and the fused
             //  small-level run start from the indices)
             const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
-            if (kernel == 1 || !identity_source(0)) {
+            if (kernel == 1 || !identity_source(0, p->tun)) {
                 HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
                 hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
                                    p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
@@ -2494,7 +2587,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));
                         hipLaunchKernelGGL(levels_small_kernel, dim3(1), dim3(1024), lds, p->stream, p->d_small + s, e - s,
                                            psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[e & 1],
-                                           static_cast<long long>(pl.ld[e]), p->d_cert + p->cert_off[e], cert_threshold());
+                                           static_cast<long long>(pl.ld[e]), p->d_cert + p->cert_off[e], cert_threshold(p->tun));
                         HIP_TRY(hipGetLastError());
                         // per-level timing: ONE event for the run, booked on its first step (an event
                         // record costs more than a fused level)
@@ -2556,10 +2649,10 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     // launch overhead.  After one eager run with the same arguments (which sizes buffers and
     // opts kernels into their LDS), the sweep is captured into a hipGraph and replayed.
     // Timing runs stay eager (they need events between the launches).
-    static const bool graphs_off = std::getenv("GENPHI_NO_GRAPH") != nullptr;
+    const bool graphs_off = p->tun.no_graph;
     const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0, p->alloc_gen};
     const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
-    const bool use_graph = !timing && !graphs_off && !(opts && (opts->reserved & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8;
+    const bool use_graph = !timing && !graphs_off && !(opts && (opts->flags & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8;
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
     if (use_graph) {
         if (!p->graph_exec || std::memcmp(key, p->graph_key, sizeof(key)) != 0) {
@@ -2667,12 +2760,12 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     int n_thr = 1;
     if (bytes >= (size_t(256) << 20)) {
         n_thr = 8;
-        if (const char *env = std::getenv("GENPHI_D2H_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(env)));
+        if (p->tun.d2h_threads > 0) n_thr = std::max(1, std::min(32, p->tun.d2h_threads));
     }
     const size_t row_bytes = N * sizeof(float);
     const size_t chunk_rows = std::max<size_t>(1, (size_t(16) << 20) / row_bytes);
     const size_t chunk_bytes = chunk_rows * row_bytes;
-    bool pinned = n_thr > 1 && std::getenv("GENPHI_D2H_PAGEABLE") == nullptr;
+    bool pinned = n_thr > 1 && !p->tun.d2h_pageable;
     if (pinned && (p->pin.size() < static_cast<size_t>(2 * n_thr) || p->pin_bytes < chunk_bytes)) {
         for (void *q : p->pin) (void)hipHostFree(q);
         for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
@@ -2856,7 +2949,7 @@ int genphi_phi_pairs(int64_t n_ind, const int64_t *ind, const int64_t *father, c
     }
     genphi_opts o;
     std::memset(&o, 0, sizeof(o));
-    o.device = device; o.reserved = GENPHI_FLAG_STORAGE_F64;
+    o.device = device; o.flags = GENPHI_FLAG_STORAGE_F64;
     rc = genphi_compute_device(pl, &o, nullptr);
     if (rc == GENPHI_OK) rc = genphi_result_entries(pl, n_pairs, rows.data(), cols.data(), out);
     const std::string keep = g_last_error;

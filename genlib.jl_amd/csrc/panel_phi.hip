@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,7 @@
 #include "planner.h"
 
 int genphi_set_error(int code, const std::string &msg);      // genphi_hip.hip
+extern "C" const char *genphi_last_error(void);
 
 namespace {
 
@@ -155,6 +157,7 @@ struct genphi_panel {
     // device
     bool on_device = false;
     int device = -1;
+    int fail_alloc_at = 0, alloc_count = 0;    // GENPHI_TEST_FAIL_ALLOC (read once in genphi_panel_create): the k-th device allocation fails
     hipStream_t stream = nullptr;
     float *panel[2] = {nullptr, nullptr};
     size_t panel_floats[2] = {0, 0};
@@ -171,6 +174,7 @@ static void panel_free_device(genphi_panel *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     auto rel = [](auto *&q) { if (q) (void)hipFree(q); q = nullptr; };
     rel(p->panel[0]); rel(p->panel[1]); rel(p->result);
+    p->panel_floats[0] = p->panel_floats[1] = 0;
     for (auto &v : {&p->d_srcA, &p->d_srcB, &p->d_ord, &p->d_send_cols, &p->d_member}) { for (int *&q : *v) rel(q); v->clear(); }
     for (int4 *&q : p->d_col) rel(q);
     p->d_col.clear();
@@ -204,6 +208,7 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
     } catch (const std::bad_alloc &) { delete p; return genphi_set_error(GENPHI_ERR_ALLOC, "out of memory while planning"); }
     if (rc) { delete p; return genphi_set_error(rc, err); }
     p->rank = rank; p->world = world;
+    if (const char *e = std::getenv("GENPHI_TEST_FAIL_ALLOC")) p->fail_alloc_at = std::atoi(e);
     const genphi::Plan &pl = p->plan;
     const int L = pl.n_levels;
     const int64_t N = pl.n_pro;
@@ -331,7 +336,7 @@ double genphi_panel_device_bytes(const genphi_panel *p)
     return 4.0 * (need[0] + need[1]);
 }
 
-static int panel_upload(genphi_panel *p, int device)
+static int panel_upload_impl(genphi_panel *p, int device)
 {
     if (p->on_device) { PN_TRY(hipSetDevice(p->device)); return GENPHI_OK; }
     int ndev = 0;
@@ -344,6 +349,10 @@ static int panel_upload(genphi_panel *p, int device)
     PN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     const genphi::Plan &pl = p->plan;
     const int L = pl.n_levels;
+    auto pmalloc = [&](void **dst, size_t bytes) -> hipError_t {
+        if (p->fail_alloc_at > 0 && ++p->alloc_count == p->fail_alloc_at) return hipErrorOutOfMemory;
+        return hipMalloc(dst, bytes);
+    };
     size_t need[2] = {0, 0};
     for (int c = 0; c < L; ++c) {
         const long long ext = c + 1 < L ? p->steps[c].n_ext : 0;
@@ -351,11 +360,11 @@ static int panel_upload(genphi_panel *p, int device)
     }
     for (int b = 0; b < 2; ++b) {
         if (!need[b]) continue;
-        PN_TRY(hipMalloc(reinterpret_cast<void **>(&p->panel[b]), need[b] * sizeof(float)));
+        PN_TRY(pmalloc(reinterpret_cast<void **>(&p->panel[b]), need[b] * sizeof(float)));
         p->panel_floats[b] = need[b];
     }
     auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
-        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+        hipError_t e = pmalloc(dst, std::max<size_t>(bytes, 16));
         if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
@@ -373,6 +382,21 @@ static int panel_upload(genphi_panel *p, int device)
     for (int c = 0; c < L; ++c)
         PN_TRY(up(p->member[c].data(), p->member[c].size() * sizeof(int), reinterpret_cast<void **>(&p->d_member[c])));
     return GENPHI_OK;
+}
+
+// Out of memory is the EXPECTED failure of the capacity path: a failed upload releases whatever it had
+// allocated, so that the handle never looks uploaded with null or partial buffers and a retry (after the
+// caller freed memory, or with more ranks) starts from scratch.
+static int panel_upload(genphi_panel *p, int device)
+{
+    const bool was = p->on_device;
+    const int rc = panel_upload_impl(p, device);
+    if (rc != GENPHI_OK && !was) {
+        const std::string keep = genphi_last_error();
+        panel_free_device(p);
+        genphi_set_error(rc, keep);
+    }
+    return rc;
 }
 
 /* Starts a sweep: Psi_1 = 1/2 I on the local columns of the top cut.  Then, for step = 0 .. n_steps-1:

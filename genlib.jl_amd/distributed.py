@@ -14,21 +14,22 @@ import numpy as np
 from . import _capi
 
 
-def _exchange(dist, send, send_cols, recv_cols, col_floats, device):
-    """All-to-all of whole columns: send_cols[d] columns to rank d, recv_cols[s] from rank s."""
+def _exchange(dist, send, recv, send_cols, recv_cols, col_floats):
+    """All-to-all of whole columns: send_cols[d] columns to rank d, recv_cols[s] from rank s, between the
+    preallocated device buffers `send` and `recv` (the used prefixes)."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
-    n_recv = int(recv_cols.sum()) * col_floats
-    recv = torch.empty(max(n_recv, 1), dtype=torch.float32, device=device)
-    if world == 1 or (int(send_cols.sum()) == 0 and n_recv == 0 and False):
-        return recv
+    if world == 1:
+        return
     in_splits = [int(c) * col_floats for c in send_cols]
     out_splits = [int(c) * col_floats for c in recv_cols]
+    n_send, n_recv = sum(in_splits), sum(out_splits)
     if dist.get_backend() == "nccl":
-        dist.all_to_all_single(recv[:n_recv], send[:sum(in_splits)], output_split_sizes=out_splits, input_split_sizes=in_splits)
-        return recv
+        # RCCL over xGMI; every rank calls it at every step (a rank with nothing to move passes empty splits)
+        dist.all_to_all_single(recv[:n_recv], send[:n_send], output_split_sizes=out_splits, input_split_sizes=in_splits)
+        return
     # gloo (rehearsals, CPU tensors): pairwise non-blocking sends / receives through host memory
-    hs = send[:sum(in_splits)].cpu()
+    hs = send[:n_send].cpu()
     hr = torch.empty(n_recv, dtype=torch.float32)
     rank = dist.get_rank()
     so = np.concatenate([[0], np.cumsum(in_splits)])
@@ -45,21 +46,30 @@ def _exchange(dist, send, send_cols, recv_cols, col_floats, device):
     for r in reqs:
         r.wait()
     recv[:n_recv].copy_(hr)
-    return recv
 
 
 def panel_sweep(pl, dist, dev):
     """One gen.phi sweep on an existing PanelPlan: begin, then pack / all-to-all / compute per level
-    step.  The result stays resident (this rank's column panel of Phi).  Returns bytes sent."""
+    step.  The result stays resident (this rank's column panel of Phi).  Returns bytes sent.
+
+    The send / receive buffers are allocated once per plan at the largest step's size.  Ordering between
+    the library's stream and torch's: genphi_panel_pack returns when the packed columns are complete
+    (the collective may start), and the collective is complete on torch's current stream before
+    genphi_panel_compute is enqueued (one stream synchronisation per step, no device-wide ones)."""
     import torch
     pl.begin(device=dev.index)
+    counts = [pl.exchange_counts(step) for step in range(pl.n_steps)]
+    bufs = getattr(pl, "_xbufs", None)
+    if bufs is None:
+        n_s = max([int(s.sum()) * cf for s, _, cf in counts] + [1])
+        n_r = max([int(r.sum()) * cf for _, r, cf in counts] + [1])
+        bufs = pl._xbufs = (torch.empty(n_s, dtype=torch.float32, device=dev), torch.empty(n_r, dtype=torch.float32, device=dev))
+    send, recv = bufs
     sent = 0
-    for step in range(pl.n_steps):
-        s_cols, r_cols, cf = pl.exchange_counts(step)
-        send = torch.empty(max(int(s_cols.sum()) * cf, 1), dtype=torch.float32, device=dev)
+    for step, (s_cols, r_cols, cf) in enumerate(counts):
         pl.pack(step, send.data_ptr())
-        recv = _exchange(dist, send, s_cols, r_cols, cf, dev)
-        torch.cuda.synchronize(dev)
+        _exchange(dist, send, recv, s_cols, r_cols, cf)
+        torch.cuda.current_stream(dev).synchronize()
         pl.compute(step, recv.data_ptr())
         sent += int(s_cols.sum()) * cf * 4
     return sent
@@ -85,11 +95,37 @@ def phi_panels(pedigree, probandIDs, dist=None, device=None, stats=None):
         pl.close()
 
 
-def replicated_levels_fit(cut_sizes, free_bytes):
-    """The size test of SURVEY.md 8(e): do two consecutive level matrices plus the result fit one GPU?
-    (pitch = multiple of 64 floats >= n + 1, as the library lays them out)"""
+def replicated_bytes(cut_sizes, wide_last=False):
+    """Device bytes of the replicated path for these cuts, as genphi_compute_device allocates them
+    (csrc/genphi_hip.hip: upload_plan / ensure_level_buffers / the result): two ping-pong buffers sized by
+    the largest EVEN and the largest ODD intermediate cut (not by the largest consecutive pair), the
+    N x pitch(N) result, a second copy of the last level when its step is WIDE (proband-order delivery),
+    the tail padding of each buffer, and ~30 bytes of index arrays per member per level.  The compacted
+    parent matrix of WIDE steps is bounded by the largest intermediate level."""
     pitch = lambda n: (n + 1 + 63) // 64 * 64          # noqa: E731
-    need = 0
-    for a, b in zip(cut_sizes[:-1], cut_sizes[1:]):
-        need = max(need, 4 * ((a + 1) * pitch(a) + (b + 1) * pitch(b)))
-    return need <= 0.92 * free_bytes
+    tail = 64 * 1024
+    need = [0, 0]
+    for c, n in enumerate(cut_sizes[:-1]):
+        need[c & 1] = max(need[c & 1], (n + 1) * pitch(n) + tail)
+    n_last = cut_sizes[-1]
+    total = need[0] + need[1] + n_last * pitch(n_last)
+    if wide_last:
+        total += (n_last + 1) * pitch(n_last) + tail
+    if max(cut_sizes[:-1], default=0) > 36863:         # WIDE steps (a source row does not fit in LDS): psi_p
+        total += max(need)
+    return 4 * total + 30 * sum(cut_sizes)
+
+
+def replicated_levels_fit(cut_sizes, free_bytes, dist=None, device=None):
+    """The size test of SURVEY.md 8(e): do the replicated level matrices plus the result fit one GPU?
+    With `dist` the answer is made COLLECTIVE (MIN over the ranks): ranks see different amounts of free
+    memory, and a rank that went down the exchange path while its peers went down the replicated one
+    would wait in a collective nobody else enters."""
+    wide_last = len(cut_sizes) >= 2 and cut_sizes[-2] > 36863      # the last step reads rows of the cut before it
+    fits = replicated_bytes(cut_sizes, wide_last=wide_last) <= 0.92 * free_bytes
+    if dist is not None and dist.get_world_size() > 1:
+        import torch
+        t = torch.tensor([1 if fits else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        fits = bool(int(t.item()))
+    return fits

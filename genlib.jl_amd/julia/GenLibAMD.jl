@@ -19,7 +19,7 @@ struct GenphiOpts              # mirrors genphi_opts (include/genphi.h)
     row_begin::Int64
     row_end::Int64
     timing::Int32
-    reserved::Int32            # flags: 1 = no hipGraph replay, 2 = Float64 level matrices (GENPHI_FLAG_STORAGE_F64)
+    flags::Int32               # GENPHI_FLAG_*: 1 = no hipGraph replay, 2 = Float64 level matrices (GENPHI_FLAG_STORAGE_F64)
 end
 const FLAG_STORAGE_F64 = Int32(2)
 

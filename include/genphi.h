@@ -47,7 +47,7 @@ typedef struct genphi_opts {
     int64_t row_begin;     /* final-level row shard [row_begin,row_end) in proband order;   */
     int64_t row_end;       /*   row_end <= 0 means "all rows" (multi-GPU: one shard/rank)   */
     int32_t timing;        /* !=0: record per-level HIP-event timings into genphi_stats     */
-    int32_t reserved;      /* flags, GENPHI_FLAG_* below (the field keeps its round-1 name)   */
+    int32_t flags;         /* GENPHI_FLAG_* below, or-ed (0 = defaults)                      */
 } genphi_opts;
 
 #define GENPHI_FLAG_NO_GRAPH     1   /* never replay the sweep from a captured hipGraph                         */

@@ -15,7 +15,21 @@ import os
 import shutil
 import sys
 
+import hashlib
+
 tag, wl = (sys.argv + ["r01", "cfg4"])[1:3]
+
+
+def csrc_sha16(root):
+    """Fingerprint of the kernel sources the counters were collected with (bench.py recomputes it and
+    says "stale" when the sources have changed since; works on the GPU box, which has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(root, "genlib.jl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(root, "profiles")
@@ -68,7 +82,7 @@ except Exception:
     pass
 sweeps = max(sweeps, 1)
 per_step = tot / sweeps / n_steps if n_steps else None
-json.dump({"workload": wl, "tag": tag, "sweeps_profiled": sweeps, "level_steps_per_sweep": n_steps,
+json.dump({"workload": wl, "tag": tag, "csrc_sha16": csrc_sha16(root), "sweeps_profiled": sweeps, "level_steps_per_sweep": n_steps,
            "hbm_bytes_per_sweep": tot / sweeps,
            "hbm_bytes_per_launch": per_step,
            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE in separate passes, "

@@ -35,6 +35,26 @@ def test_shard_rows_tile_the_matrix():
             assert all(0 <= a <= b <= n for a, b in sh)
 
 
+def test_replicated_memory_model_matches_the_allocations():
+    """distributed.replicated_bytes models what genphi_compute_device allocates (two ping-pong buffers by
+    the largest even / odd intermediate cut, the result, tail padding, index arrays), not the largest pair
+    of consecutive levels: the size test that chooses between replicated levels and column panels."""
+    sys.path.insert(0, ROOT)
+    from genlib_jl_amd import distributed as gdist
+    pitch = lambda n: (n + 1 + 63) // 64 * 64      # noqa: E731
+    cuts = [10, 5000, 200, 7000, 3000, 9000, 100, 4000]           # the two largest intermediate cuts are not consecutive
+    b = gdist.replicated_bytes(cuts)
+    even, odd = max(cuts[0:-1:2]), max(cuts[1:-1:2])
+    want = 4 * ((even + 1) * pitch(even) + (odd + 1) * pitch(odd) + 4000 * pitch(4000))
+    assert want <= b <= want + 4 * 2 * 65536 + 30 * sum(cuts) + 1024
+    pair = max(4 * ((a + 1) * pitch(a) + (c + 1) * pitch(c)) for a, c in zip(cuts[:-1], cuts[1:]))
+    assert b > pair                                                # the old pairwise model under-estimated
+    assert gdist.replicated_levels_fit(cuts, b / 0.92 + 1) and not gdist.replicated_levels_fit(cuts, b / 0.92 - 1e6)
+    # cfg4: 3.8 GB + 2.4 GB of level matrices + the 40 GB result
+    cfg4 = [24301] * 24 + [24650, 25190, 26502, 30976, 100000]
+    assert 45e9 < gdist.replicated_bytes(cfg4) < 48e9
+
+
 def test_two_rank_gloo_dry_run():
     d = _launch(2, ["--workload", "cfg2", "--dry-run"], 29533)
     assert d["dry_run"] and d["n_gpus"] == 2 and d["n_probands"] == 140

@@ -986,3 +986,44 @@ def test_cfg4o_downscaled_twin(gen, oracle, monkeypatch):
     pl.close()
     for k in ("GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_FAST"):
         monkeypatch.delenv(k, raising=False)
+
+
+def test_failed_upload_leaves_a_clean_plan(gen, oracle, monkeypatch):
+    """Out of memory in the middle of an upload (the expected failure of large plans and of the capacity
+    path): the call fails loudly, the plan / panel handle is back in the never-uploaded state (no
+    half-allocated buffers behind an 'already on device' flag), and a retry uploads from scratch and
+    gives the oracle's matrix.  GENPHI_TEST_FAIL_ALLOC = k makes the k-th device allocation fail."""
+    from genlib_jl_amd import synth, _capi
+    ind, fa, mo, sex, pro = synth.random_mating(3000, 300, 8, skip_permille=100)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", "300")             # WIDE steps: psi_p and its certificates are allocated too
+        for k in range(1, 12):
+            monkeypatch.setenv("GENPHI_TEST_FAIL_ALLOC", str(k))
+            pl = gen.plan(ped, pro)
+            failed = False
+            try:
+                got = pl.compute()
+            except gen.GenphiDeviceError:
+                failed = True
+                got = pl.compute()                                        # the retry starts from scratch
+            _assert_equal(got, want)
+            pl.close()
+            if not failed:
+                assert k > 6                                              # fewer allocations than k: nothing to inject
+                break
+        monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS", raising=False)
+    for k in (1, 2, 5):
+        monkeypatch.setenv("GENPHI_TEST_FAIL_ALLOC", str(k))
+        pp = _capi.PanelPlan(ped.ind, ped.father, ped.mother, np.asarray(pro, dtype=np.int64), 0, 1)
+        with pytest.raises(gen.GenphiDeviceError):
+            pp.begin()
+        pp.begin()                                                        # second attempt: clean upload
+        for step in range(pp.n_steps):
+            pp.pack(step, 0)
+            pp.compute(step, 0)
+        _assert_equal(pp.result_to_host(), want)
+        pp.close()
+    monkeypatch.delenv("GENPHI_TEST_FAIL_ALLOC", raising=False)
