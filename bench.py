@@ -167,24 +167,34 @@ def dry_run(args, rank, world):
 
 
 def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits):
-    """N > 1 with storage-sharded level matrices: every rank holds a column panel of every level and
-    the ranks exchange parent columns before every level step (genlib_jl_amd/distributed.py)."""
+    """Storage-sharded level matrices: every rank holds a column panel of every level and the ranks
+    exchange parent columns before every level step (genlib_jl_amd/distributed.py).  world = 1 runs the
+    same path on one rank (no exchange): the panel kernels' own number."""
     import torch
     from genlib_jl_amd import _capi, distributed as gdist
     dev = torch.device("cuda", local_rank)
     pl = _capi.PanelPlan(ped.ind, ped.father, ped.mother, np.asarray(pro, dtype=np.int64), rank, world)
     n = pl.n_probands
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(max(args.warmup, 1)):
         sent = gdist.panel_sweep(pl, dist, dev)
-    dist.barrier(); torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sent = gdist.panel_sweep(pl, dist, dev)
-    dist.barrier(); torch.cuda.synchronize()
+    barrier()
     wall = time.perf_counter() - t0
-    tt = torch.tensor([wall, float(sent)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall = float(tt[0].item())
+    if dist is not None:
+        tt = torch.tensor([wall, float(sent)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, sent_max = float(tt[0].item()), float(tt[1].item())
+    else:
+        sent_max = float(sent)
     if rank == 0:
         K = args.steps
         B = sum(4.0 * (a * a + b * b) for a, b in zip(cut_sizes[:-1], cut_sizes[1:]))
@@ -195,17 +205,25 @@ def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes,
             "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(cut_sizes), "storage": "f32",
-                       "parallelism": f"column panels x{world}: every level storage-sharded, one all-to-all of parent columns per level step",
+                       "parallelism": f"column panels x{world}: every level storage-sharded, one all-to-all of parent columns per level step"
+                                      + (" (all ranks share one GPU: rehearsal)" if args.single_device and world > 1 else ""),
                        "why_exchange": "forced" if fits else "two level matrices do not fit one GPU",
-                       "exchange_bytes_sent_per_rank_max": float(tt[1].item()),
-                       "panel_device_bytes": pl.device_bytes, "max_cut": max(cut_sizes)},
-            "roofline": {"bound": "hbm", "kernel": "panel_level_kernel (capacity path: per-entry gathers)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS / world, "traffic": None,
-                         "note": "achieved = algorithmic bytes of the whole job / time; frac is per GPU"},
+                       "exchange_bytes_sent_per_rank_max": sent_max,
+                       "panel_device_bytes": pl.device_bytes, "max_cut": max(cut_sizes),
+                       "panel_step_modes": pl.step_modes() if hasattr(pl, "step_modes") else None,
+                       "timed": "host wall clock around whole sweeps (pack, exchange through "
+                                + ("RCCL" if args.backend == "nccl" and world > 1 else "host memory (gloo)" if world > 1 else "nothing: one rank")
+                                + ", unpack, level kernels), max over ranks"},
+            "roofline": {"bound": "hbm", "kernel": "level_full_kernel / level_split_fast_kernel on column panels (panel_level_kernel beyond LDS)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS / (1 if args.single_device else world), "traffic": None,
+                         "note": "achieved = algorithmic bytes of the whole job (4 sum(n_k^2 + n_{k+1}^2)) / time, exchange included; "
+                                 "frac is per GPU (ranks that share one GPU in a rehearsal count as one)"},
         }), flush=True)
     pl.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -254,7 +272,7 @@ def main():
 
     import genlib_jl_amd as gen
     ped, pro, desc = load_workload(args.workload)
-    if world > 1:
+    if world > 1 or args.exchange:
         from genlib_jl_amd import distributed as gdist
         probe = gen.plan(ped, pro)
         cut_sizes = probe.levels()[0]

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
     "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
-    "genphi_panel_create", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
+    "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
     "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_result_to_host",
     "genphi_panel_destroy",
 ]
@@ -125,6 +125,8 @@ def lib():
         L.genphi_panel_create.restype = C.c_int
         L.genphi_panel_n_steps.argtypes = [C.c_void_p]
         L.genphi_panel_n_steps.restype = C.c_int64
+        L.genphi_panel_step_mode.argtypes = [C.c_void_p, C.c_int32]
+        L.genphi_panel_step_mode.restype = C.c_int
         L.genphi_panel_n_probands.argtypes = [C.c_void_p]
         L.genphi_panel_n_probands.restype = C.c_int64
         L.genphi_panel_result_rows.argtypes = [C.c_void_p, _I64P, _I64P]
@@ -465,6 +467,11 @@ class PanelPlan:
         if rc:
             _raise(rc)
         return a.value, b.value
+
+    def step_modes(self):
+        """Kernel family of every level step on this rank's panel: 0 FULL, 1 SPLIT (the row kernels of the
+        dense path on the local columns), 2 per-entry kernel (panel rows too long for LDS, or GENPHI_PANEL_NAIVE)."""
+        return [int(lib().genphi_panel_step_mode(self._h, k)) for k in range(self.n_steps)]
 
     def exchange_counts(self, step):
         """(columns to send per rank, columns to receive per rank, floats per column) before level step `step`."""

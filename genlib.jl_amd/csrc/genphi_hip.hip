@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "../../include/genphi.h"
+#include "panel_launch.h"
 #include "planner.h"
 
 using genphi::LevelStep;
@@ -126,11 +127,19 @@ struct LevelArgs {
     unsigned chunk_magic;    // SPLIT: floor(2^32 / n_chunks) + 1, so that item / n_chunks = umulhi(item, chunk_magic); 0 when n_chunks == 1
     const int *gcnt;         // SPLIT: [0] certified groups, [1] the others (of this launch's group list)
     unsigned cert_thresh;    // bits of the smallest certified value minus one (test hook raises it)
+    int cert_fast;           // FULL: rows whose source rows are certified take the grouping-free body (0: grouping-exact body only)
+    // Rows and columns of a launch are the same members, except in a COLUMN PANEL (storage-sharded levels,
+    // panel_phi.hip): there a launch computes every row of the cut for the rank's LOCAL columns only, and the
+    // source "row" is a row of the rank's extended panel (own + received columns; pk indexes into it).
+    const int *ord_col;      // rank word per column (= ord unless panel)
+    const int *diag_col;     // panel: local column of row member i, or -1 (nullptr: column i)
+    const int2 *pdesc;       // panel, SPLIT: per work row (local column of the member or -1, panel column of its A source)
+    int zrow;                // index of the all-zero "none" row of `out` (= n unless panel: the cut's size)
 };
 
 // ---- shared pieces of the row kernels --------------------------------------------------------
 struct RowCtx {
-    int i, Ai, Bi, ord_i;
+    int i, Ai, Bi, ord_i, dcol;
     bool new_i, hasB;
     const float *rowA, *rowB;
     float *orowp;
@@ -155,7 +164,11 @@ __device__ __forceinline__ RowCtx row_setup(const LevelArgs &p)
     r.sc_i = r.new_i ? 0.5 : 1.0;
     // diagonal of a new member: 1/2 + Psi[A][B]/2 (zero when a parent is missing)
     r.diag = 0.f;
-    if (r.new_i) r.diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(r.rowA[r.Bi]));
+    r.dcol = p.diag_col ? p.diag_col[r.i] : r.i;      // column that holds the member's own entry (-1: not among this launch's columns)
+    if (r.new_i && r.dcol >= 0) {
+        const int colB = p.diag_col ? static_cast<int>(p.pk[r.dcol] >> 16) : r.Bi;      // B's column in the staged row
+        r.diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(r.rowA[colB]));
+    }
     return r;
 }
 
@@ -183,13 +196,58 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
     float *sA = lds;
     float *sB = lds + p.lds_row;
     if (blockIdx.x == (unsigned)p.n_rows) {        // extra block: the all-zero "none" row of this level
-        float *zr = p.out + (long long)p.n * p.ld;
+        float *zr = p.out + (long long)p.zrow * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += blockDim.x) zr[j] = 0.f;
         return;
     }
     const RowCtx r = row_setup(p);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nvec = p.lds_row >> 2;               // columns [0, lds_row) include the zero column
+    // Certified source rows (see cert_key): every Float64 partial sum of an entry is exact, so the grouping of
+    // the reference's recursion cannot change the result and the entry is RN32(((a + b) + (c + d)) 2^e) in any
+    // order.  The two source rows are then ADDED WHILE THEY ARE STAGED -- S[k] = A[k] + B[k] as ONE Float64 per
+    // source column, in the LDS bytes the two Float32 rows would take -- and an entry is RN32((S[A_j] + S[B_j]) 2^e):
+    // two 8-byte gathers, one add, one scale, one conversion per entry instead of four gathers, four conversions,
+    // three adds and the rank selects; no rank words are loaded.  Workgroup-uniform branch; rows with an
+    // uncertified source take the grouping-exact body below (tests force both on the same inputs).
+    if (p.cert_fast && (p.cert_prev[r.Ai] | p.cert_prev[r.Bi]) == 0) {
+        double *S = reinterpret_cast<double *>(lds);
+        const float4 *a4 = reinterpret_cast<const float4 *>(r.rowA), *b4 = reinterpret_cast<const float4 *>(r.rowB);
+        double2 *S2 = reinterpret_cast<double2 *>(S);
+        for (int base = tid; base < nvec; base += 2 * nt) {           // all loads of a batch in flight before the first LDS write
+            const int k0 = base, k1 = min(base + nt, nvec - 1);
+            const float4 x0 = a4[k0], x1 = a4[k1];
+            float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
+            if (r.hasB) { y0 = b4[k0]; y1 = b4[k1]; }
+            S2[2 * k0] = make_double2(static_cast<double>(x0.x) + static_cast<double>(y0.x), static_cast<double>(x0.y) + static_cast<double>(y0.y));
+            S2[2 * k0 + 1] = make_double2(static_cast<double>(x0.z) + static_cast<double>(y0.z), static_cast<double>(x0.w) + static_cast<double>(y0.w));
+            S2[2 * k1] = make_double2(static_cast<double>(x1.x) + static_cast<double>(y1.x), static_cast<double>(x1.y) + static_cast<double>(y1.y));
+            S2[2 * k1 + 1] = make_double2(static_cast<double>(x1.z) + static_cast<double>(y1.z), static_cast<double>(x1.w) + static_cast<double>(y1.w));
+        }
+        __syncthreads();
+        const double sc = r.new_i ? 0.25 : 0.5;    // row weight times the column's 1/2 (a dragged column is A = B = itself)
+        unsigned ckf = 0xffffffffu;
+        for (int j0 = tid; j0 < p.n; j0 += U * nt) {
+            unsigned pk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pk[u] = p.pk[min(j0 + u * nt, p.n - 1)];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = static_cast<float>((S[pk[u] & 0xffff] + S[pk[u] >> 16]) * sc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * nt;
+                if (j < p.n) {
+                    const float val = (j == r.dcol && r.new_i) ? r.diag : v[u];
+                    ckf = min(ckf, cert_key(val));
+                    r.orowp[j] = val;
+                }
+            }
+        }
+        if (p.cert_out && ckf < p.cert_thresh) p.cert_out[r.i] = 1;
+        for (long long j = p.n + tid; j < p.width; j += nt) r.orowp[j] = 0.f;
+        return;
+    }
     stage_row<4>(sA, r.rowA, nvec, tid, nt);
     if (r.hasB) stage_row<4>(sB, r.rowB, nvec, tid, nt);
     __syncthreads();
@@ -201,7 +259,7 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         for (int u = 0; u < U; ++u) {
             const int j = min(j0 + u * nt, p.n - 1);
             pk[u] = p.pk[j];
-            oj[u] = POS_ORD ? 0 : p.ord[j];
+            oj[u] = POS_ORD ? 0 : p.ord_col[j];
         }
         float v[U];
         if (r.hasB) {
@@ -223,7 +281,7 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * nt;
             if (j < p.n) {
-                const float val = (j == r.i && r.new_i) ? r.diag : v[u];
+                const float val = (j == r.dcol && r.new_i) ? r.diag : v[u];
                 ck = min(ck, cert_key(val));
                 r.orowp[j] = val;
             }
@@ -346,7 +404,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         return n_items;
     };
     if (p.zero_row && blockIdx.x == 0) {                  // the all-zero "none" row of this level
-        float *zr = p.out + (long long)p.n * p.ld;
+        float *zr = p.out + (long long)p.zrow * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
     if (n_items == 0) return;                             // nothing uncertified in this launch
@@ -458,7 +516,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 int oj[CPT];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const i4_t v = ld_off<i4_t>(p.ord, (cb + q * 4 * NT + tl * 4) * 4u);
+                    const i4_t v = ld_off<i4_t>(p.ord_col, (cb + q * 4 * NT + tl * 4) * 4u);
                     oj[4 * q] = v.x; oj[4 * q + 1] = v.y; oj[4 * q + 2] = v.z; oj[4 * q + 3] = v.w;
                 }
                 const int o0 = desc[wb].w & kOrdMask;
@@ -514,7 +572,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             float *orowp = p.out + (long long)orow * p.ld;
             const int e_ij = (new_i ? -1 : 0) - 1;       // 2^e: row weight times the column's 1/2
             // diagonal of a new member: 1/2 + Psi[A][B]/2 = 1/2 + Psi[B][A]/2 (bit-symmetric)
-            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
+            const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[p.pdesc ? p.pdesc[w].y : Ai]));
             const int qk = w - wb;                      // which child of the group (wave-uniform)
             const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -528,7 +587,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                     const int k = 4 * q + e;
                     const unsigned j = jq + e;
                     const float c = sR[pk[k] & 0xffff], d = sR[pk[k] >> 16];
-                    const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);
+                    const bool i_hi = POS_ORD ? (j < (unsigned)ri) : (bool)((hi_bits >> k) & 1u);     // (POS_ORD is never used on panels)
                     vq[e] = combine_e(pa[k], pb[k], c, d, i_hi, e_ij);
                 }
                 ck = min(ck, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ck));
@@ -538,10 +597,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             if (p.cert_out && ck < p.cert_thresh) p.cert_out[ri] = 1;         // plain store: the words only ever go 0 -> 1
             // the diagonal entry of a new member is patched by the thread that owns its column
             // (same thread as the quad store above, so the two stores stay ordered)
-            if (new_i) {
-                const unsigned r = (unsigned)ri - cb;
-                if ((unsigned)ri >= cb && (unsigned)ri < ce && ((r >> 2) & (NT - 1)) == tl)
-                    st_off<float>(orowp, (unsigned)ri * 4u, diag);
+            if (new_i && dcol >= 0) {
+                const unsigned r = (unsigned)dcol - cb;
+                if ((unsigned)dcol >= cb && (unsigned)dcol < ce && ((r >> 2) & (NT - 1)) == tl)
+                    st_off<float>(orowp, (unsigned)dcol * 4u, diag);
             }
             wfin_b = w + 1;
             wfin_e = (nextB == p.n_prev) ? we : w + 1;
@@ -554,6 +613,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             __builtin_assume(tlf < NT);
             const int4 df = desc[wf];
             const bool new_f = df.w < 0;
+            const unsigned dcol_f = static_cast<unsigned>(p.pdesc ? p.pdesc[wf].x : df.x);     // (-1 matches no column)
             float *orowp = p.out + (long long)df.y * p.ld;
             const int e_ij = (new_f ? -1 : 0) - 1;
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -567,7 +627,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                     const int k = 4 * q + e;
                     const float v = combine_e(__uint_as_float(__float_as_uint(pa[k]) ^ z1),
                                               __uint_as_float(__float_as_uint(pb[k]) ^ z1), 0.f, 0.f, true, e_ij);
-                    vq[e] = (jq + e == (unsigned)df.x && new_f) ? 0.5f : v;
+                    vq[e] = (jq + e == dcol_f && new_f) ? 0.5f : v;
                 }
                 ckf = min(ckf, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ckf));
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
@@ -630,7 +690,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         return n_items;
     };
     if (p.zero_row && blockIdx.x == 0) {                  // the all-zero "none" row of this level
-        float *zr = p.out + (long long)p.n * p.ld;
+        float *zr = p.out + (long long)p.zrow * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
     if (n_items == 0) return;                             // no certified group in this launch
@@ -726,7 +786,8 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             const int ri = dsc.x, orow = dsc.y;
             float *orowp = p.out + (long long)orow * p.ld;
             // a row with a B source is a new member with both parents: weight 1/2 x 1/2 per column
-            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[Ai]));
+            const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[p.pdesc ? p.pdesc[w].y : Ai]));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
             unsigned ck = 0xffffffffu;
 #pragma unroll
@@ -742,10 +803,10 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
                 if (CERT) { ck = min(ck, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ck)); }
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
-            {
-                const unsigned r = (unsigned)ri - cb;
-                if ((unsigned)ri >= cb && (unsigned)ri < ce && ((r >> 2) & (NT - 1)) == tl)
-                    st_off<float>(orowp, (unsigned)ri * 4u, diag);
+            if (dcol >= 0) {
+                const unsigned r = (unsigned)dcol - cb;
+                if ((unsigned)dcol >= cb && (unsigned)dcol < ce && ((r >> 2) & (NT - 1)) == tl)
+                    st_off<float>(orowp, (unsigned)dcol * 4u, diag);
             }
             if (CERT) { if (ck < p.cert_thresh) p.cert_out[ri] = 1; }     // plain store: the words only ever go 0 -> 1
             wfin_b = w + 1;
@@ -758,6 +819,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             __builtin_assume(tlf < NT);
             const int4 df = desc[wf];
             const bool new_f = df.w < 0;
+            const unsigned dcol_f = static_cast<unsigned>(p.pdesc ? p.pdesc[wf].x : df.x);     // (-1 matches no column)
             float *orowp = p.out + (long long)df.y * p.ld;
             const double sc = new_f ? 1.0 : 2.0;          // pab carries 1/4; a dragged row weighs 1, not 1/2
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -769,7 +831,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = static_cast<float>(pab[4 * q + e] * sc);
-                    vq[e] = (jq + e == (unsigned)df.x && new_f) ? 0.5f : v;
+                    vq[e] = (jq + e == dcol_f && new_f) ? 0.5f : v;
                 }
                 if (CERT) { ckf = min(ckf, min(min(cert_key(vq[0]), cert_key(vq[1])), min(cert_key(vq[2]), cert_key(vq[3])))); asm volatile("" : "+v"(ckf)); }
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
@@ -1115,6 +1177,59 @@ __global__ void level_naive64_kernel(const double *__restrict__ psi, long long l
     }
     (void)n_prev; (void)n;
     out[orow * ld + j] = v;
+}
+
+// Float64 storage, cuts whose two source rows fit in LDS (2 x 8 bytes x (n_prev + 1) <= 160 KB): the FULL
+// kernel's shape -- one workgroup per output row, both source rows staged whole with 16-byte coalesced loads,
+// four 8-byte LDS gathers per entry, coalesced row stores -- with the reference's grouping (src/compute.jl:66-95
+// climbs the higher-ranked individual first) and no rounding to Float32.  Same arguments as level_naive64_kernel.
+__global__ void __launch_bounds__(512)
+level_full64_kernel(const double *__restrict__ psi, long long ld_prev, int n_prev, double *__restrict__ out, long long ld,
+                    const int *__restrict__ srcA, const int *__restrict__ srcB, const int *__restrict__ ord,
+                    const int *__restrict__ rows, const int *__restrict__ out_rows, const int *__restrict__ colmap, int n_cols,
+                    int lds_row)
+{
+    extern __shared__ double lds64[];
+    double *sA = lds64, *sB = lds64 + lds_row;
+    const int w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int i = rows ? rows[w] : w;
+    const long long orow = out_rows ? out_rows[w] : i;
+    const int Ai = srcA[i], Bi = srcB[i], oi = ord[i];
+    const bool hasB = Bi != n_prev;
+    {
+        const double2 *a2 = reinterpret_cast<const double2 *>(psi + (long long)Ai * ld_prev);
+        const double2 *b2 = reinterpret_cast<const double2 *>(psi + (long long)Bi * ld_prev);
+        double2 *sA2 = reinterpret_cast<double2 *>(sA), *sB2 = reinterpret_cast<double2 *>(sB);
+        const int nvec = lds_row >> 1;
+        for (int base = tid; base < nvec; base += 4 * nt) {
+            double2 ra[4], rb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int q = min(base + k * nt, nvec - 1); ra[k] = a2[q]; rb[k] = hasB ? b2[q] : make_double2(0.0, 0.0); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int q = min(base + k * nt, nvec - 1); sA2[q] = ra[k]; sB2[q] = rb[k]; }
+        }
+    }
+    __syncthreads();
+    const bool new_i = oi < 0;
+    const int ord_i = oi & kOrdMask;
+    double *orowp = out + orow * ld;
+    for (int j = tid; j < ld; j += nt) {
+        double v = 0.0;
+        if (j < n_cols) {
+            const int jm = colmap ? colmap[j] : j;
+            const int Aj = srcA[jm], Bj = srcB[jm], oj = ord[jm];
+            if (jm == i && new_i) {
+                v = 0.5 + 0.5 * sA[Bi];
+            } else {
+                const double sc = (new_i ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
+                const double a = sA[Aj], b = sA[Bj], c = sB[Aj], d = sB[Bj];
+                const bool i_hi = ord_i > (oj & kOrdMask);
+                const double x = i_hi ? b : c, y = i_hi ? c : b;
+                v = ((a + x) + (y + d)) * sc;
+            }
+        }
+        orowp[j] = v;
+    }
 }
 
 __global__ void half_identity64_kernel(double *m, long long ld, int n, const int *out_rows, int n_rows, const int *colmap)
@@ -1694,7 +1809,7 @@ void genphi_plan_destroy(genphi_plan *plan)
 static hipError_t plan_malloc(genphi_plan *p, void **ptr, size_t bytes)
 {
     if (p->tun.fail_alloc_at > 0 && ++p->alloc_count == p->tun.fail_alloc_at) return hipErrorOutOfMemory;
-    return plan_malloc(p, ptr, bytes);
+    return hipMalloc(ptr, bytes);
 }
 
 // upload the flat index arrays once
@@ -2058,6 +2173,122 @@ static LevelCtx main_ctx(genphi_plan *p, int step)
     return c;
 }
 
+// What a FULL / SPLIT launch needs from its owner (a plan's level step, or a rank's column panel)
+struct LaunchRes {
+    hipStream_t stream;
+    int n_cus;
+    const Tuning *tun;
+    int *queue;              // 16 work-queue counters, zeroed before the launch
+    int *gcnt;               // 4 group counters, zeroed before the launch
+    int *glist_f, *glist_s;  // device-compacted group lists of the certified-rows / grouping-exact SPLIT kernels
+};
+
+// FULL or SPLIT launch of a prepared LevelArgs.  src_width = floats of a staged source row including its zero
+// column (n_prev + 1; on a panel: own + received columns + 1); width = columns a row kernel writes.
+static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, int64_t src_width, int64_t width, int kernel,
+                       const DeviceGroups &dg)
+{
+    const int n_rows = a.n_rows;
+    const int lds_row = static_cast<int>((src_width + 3) / 4 * 4);
+    if (mode == genphi::kModeFull) {
+        a.lds_row = lds_row;
+        const size_t lds = 2 * static_cast<size_t>(lds_row) * sizeof(float);
+        const int bs = block_size_for(std::max<int64_t>(a.n, src_width), *R.tun);
+        if (pos_ord) {
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, true>), lds));
+            hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows + a.zero_row), dim3(bs), lds, R.stream, a);
+        } else {
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, false>), lds));
+            hipLaunchKernelGGL((level_full_kernel<4, false>), dim3(n_rows + a.zero_row), dim3(bs), lds, R.stream, a);
+        }
+    } else if (mode == genphi::kModeSplit) {
+        a.lds_row = lds_row;
+        const int per_row4 = lds_row / 4;                                // float4 per staged row
+        const int stg1k = (per_row4 + 1023) / 1024;
+        // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
+        const int stg_inst = stg1k <= 2 ? 2 : (stg1k <= 4 ? 4 : (stg1k <= 6 ? 6 : (stg1k <= 7 ? 7 : (stg1k <= 8 ? 8 : 9))));
+        const bool no_fast = R.tun->no_fast;                                    // test / A-B hook: grouping-exact kernel only
+        const bool certs = !no_fast && kernel == 0;
+        int *queue = R.queue;                                                 // zeroed at the start of the sweep
+        int *gcnt = R.gcnt;
+        // geometry of the grouping-exact kernel (1024 threads)
+        constexpr int nt_s = 1024;
+        // LDS must also absorb the unconditional over-write past the row's end
+        const size_t lds_stage_s = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt_s * 16);
+        const size_t lds = lds_stage_s + 32 + (GENPHI_WG_TIMES ? 128 : 0);
+        const int per_thread = static_cast<int>((width + nt_s - 1) / nt_s);     // the padding columns [n, ld) are written too
+        // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
+        int max_cpt;
+        if (pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
+        else           max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 8 ? 20 : 16);
+        const int env_cpt = R.tun->max_cpt;                                     // tuning hook: smaller chunks
+        if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
+        const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
+        const int cpt = (per_thread + n_chunks - 1) / n_chunks;
+        const long long n_items = static_cast<long long>(dg.n_groups_s) * n_chunks;
+        if (certs) {
+            // ---- certified groups: level_split_fast_kernel ----
+            LevelArgs f = a;
+            int f_nt = 1024, f_chunks = 1 << 30, f_stg = stg_inst;
+            const int force_nt = R.tun->fast_nt;                                // test / tuning hook
+            for (int nt : {1024, 512}) {
+                if (force_nt && nt != force_nt) continue;
+                int stg = (per_row4 + nt - 1) / nt;
+                if (nt == 512) stg = stg <= 12 ? 12 : (stg <= 14 ? 14 : (stg <= 16 ? 16 : 18)); else stg = stg_inst;
+                const int pt = static_cast<int>((width + nt - 1) / nt);
+                int mc = fast_max_cpt(nt, stg);
+                if (env_cpt >= 4) mc = std::min(mc, env_cpt * (1024 / nt) / 4 * 4);
+                const int nch = (pt + mc - 1) / mc;
+                if (nch < f_chunks) { f_chunks = nch; f_nt = nt; f_stg = stg; }
+            }
+            const int f_pt = static_cast<int>((width + f_nt - 1) / f_nt);
+            const int f_cpt = ((f_pt + f_chunks - 1) / f_chunks + 3) / 4 * 4;
+            const long long f_items = static_cast<long long>(dg.n_groups) * f_chunks;
+            // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
+            // group list) -> glist_s / gcnt[3]: decided on the device, per launch
+            int *glist_f = R.glist_f, *glist_s = R.glist_s;
+            int *gcnt_s = gcnt;                                               // [1] = groups of the grouping-exact kernel
+            if (dg.span_s) {
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp,
+                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp_s,
+                                   static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
+                                   gcnt + 2);
+                gcnt_s = gcnt + 2;
+            } else {                                                          // both kernels walk the same group list: one pass
+                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp,
+                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, glist_s, gcnt);
+            }
+            HIP_TRY(hipGetLastError());
+            f.glist = glist_f; f.gcnt = gcnt;
+            f.chunk_magic = chunk_magic_for(f_chunks);
+            const size_t f_lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(f_stg) * f_nt * 16);
+            f.slot_off = static_cast<int>(f_lds_stage / sizeof(float));
+            f.chunk_cols = f_cpt * f_nt;
+            f.n_chunks = f_chunks;
+            f.n_groups = dg.n_groups;
+            const int f_grid = static_cast<int>(std::min<long long>(R.n_cus, (f_items + 7) / 8 * 8));
+            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.grp, queue)
+                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.grp, queue));
+            a.zero_row = 0;                                                   // the fast launch wrote the "none" row
+            a.glist = glist_s; a.gcnt = gcnt_s;
+        }
+        // ---- the other groups (all of them without certificates): level_split_kernel ----
+        a.slot_off = static_cast<int>(lds_stage_s / sizeof(float));
+        a.chunk_cols = (cpt + 3) / 4 * 4 * nt_s;                        // whole quads of columns per thread
+        a.n_chunks = n_chunks;
+        a.chunk_magic = chunk_magic_for(n_chunks);
+        a.n_groups = dg.n_groups_s;
+        const int grid = static_cast<int>(std::min<long long>(R.n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
+        HIP_TRY(pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.grp_s, queue + 8)
+                          : launch_split<false>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.grp_s, queue + 8));
+    } else {
+        return fail(GENPHI_ERR_ARG, "internal: launch_rows takes FULL and SPLIT steps");
+    }
+    HIP_TRY(hipGetLastError());
+    return GENPHI_OK;
+}
+
 static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, float *out, const int *rows,
                         const int *out_rows, int n_rows, int kernel, const DeviceGroups &dg)
 {
@@ -2076,6 +2307,8 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
     a.cert_out = out_rows == nullptr ? cx.cert_out : nullptr;
     a.glist = nullptr; a.gcnt = nullptr; a.chunk_magic = 0;
     a.cert_thresh = cert_threshold(p->tun);
+    a.cert_fast = (kernel == 0 && !p->tun.no_fast && cx.cert_prev != nullptr) ? 1 : 0;
+    a.ord_col = d.ord; a.diag_col = nullptr; a.pdesc = nullptr; a.zrow = a.n;
     if (n_rows <= 0) {
         // nothing to compute (a row shard whose ancestors do not reach this level), but the next level
         // still reads this level's all-zero "none" row for its parentless members
@@ -2083,7 +2316,6 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
             HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
         return GENPHI_OK;
     }
-    const int lds_row = static_cast<int>((s.n_prev + 1 + 3) / 4 * 4);
     if (kernel == 1) {
         dim3 grid(static_cast<unsigned>(n_rows), static_cast<unsigned>((s.ld + 255) / 256));
         hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
@@ -2091,103 +2323,47 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
         hipLaunchKernelGGL(level_identity_kernel, dim3(static_cast<unsigned>(n_rows)), dim3(256), 0, p->stream, a);
         if (out_rows == nullptr)         // intermediate level: its all-zero "none" row
             HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
-    } else if (s.mode == genphi::kModeFull) {
-        a.lds_row = lds_row;
-        const size_t lds = 2 * static_cast<size_t>(lds_row) * sizeof(float);
-        const int bs = block_size_for(std::max(s.n, s.n_prev), p->tun);
-        if (s.pos_ord) {
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, true>), lds));
-            hipLaunchKernelGGL((level_full_kernel<4, true>), dim3(n_rows + a.zero_row), dim3(bs), lds, p->stream, a);
-        } else {
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full_kernel<4, false>), lds));
-            hipLaunchKernelGGL((level_full_kernel<4, false>), dim3(n_rows + a.zero_row), dim3(bs), lds, p->stream, a);
-        }
-    } else if (s.mode == genphi::kModeSplit) {
-        a.lds_row = lds_row;
-        const int per_row4 = lds_row / 4;                                // float4 per staged row
-        const int stg1k = (per_row4 + 1023) / 1024;
-        // staging instantiations; the planner keeps lds_row <= 36864 floats (9 * 1024 float4 + the queue slots <= 160 KB)
-        const int stg_inst = stg1k <= 2 ? 2 : (stg1k <= 4 ? 4 : (stg1k <= 6 ? 6 : (stg1k <= 7 ? 7 : (stg1k <= 8 ? 8 : 9))));
-        const bool no_fast = p->tun.no_fast;                                    // test / A-B hook: grouping-exact kernel only
-        const bool certs = !no_fast && kernel == 0;
-        int *queue = p->d_queues + 16 * step;                                 // zeroed at the start of the sweep
-        int *gcnt = p->d_gcnt + 4 * step;
-        // geometry of the grouping-exact kernel (1024 threads)
-        constexpr int nt_s = 1024;
-        // LDS must also absorb the unconditional over-write past the row's end
-        const size_t lds_stage_s = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(stg_inst) * nt_s * 16);
-        const size_t lds = lds_stage_s + 32 + (GENPHI_WG_TIMES ? 128 : 0);
-        const int per_thread = static_cast<int>((s.width + nt_s - 1) / nt_s);     // the padding columns [n, ld) are written too
-        // register budget of the instantiations (all spill-free: a spill stalls the pipeline)
-        int max_cpt;
-        if (s.pos_ord) max_cpt = stg_inst <= 7 ? 24 : (stg_inst == 8 ? 20 : 16);
-        else           max_cpt = stg_inst <= 4 ? 24 : (stg_inst <= 8 ? 20 : 16);
-        const int env_cpt = p->tun.max_cpt;                                     // tuning hook: smaller chunks
-        if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
-        const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
-        const int cpt = (per_thread + n_chunks - 1) / n_chunks;
-        const long long n_items = static_cast<long long>(dg.n_groups_s) * n_chunks;
-        if (certs) {
-            // ---- certified groups: level_split_fast_kernel ----
-            LevelArgs f = a;
-            int f_nt = 1024, f_chunks = 1 << 30, f_stg = stg_inst;
-            const int force_nt = p->tun.fast_nt;                                // test / tuning hook
-            for (int nt : {1024, 512}) {
-                if (force_nt && nt != force_nt) continue;
-                int stg = (per_row4 + nt - 1) / nt;
-                if (nt == 512) stg = stg <= 12 ? 12 : (stg <= 14 ? 14 : (stg <= 16 ? 16 : 18)); else stg = stg_inst;
-                const int pt = static_cast<int>((s.width + nt - 1) / nt);
-                int mc = fast_max_cpt(nt, stg);
-                if (env_cpt >= 4) mc = std::min(mc, env_cpt * (1024 / nt) / 4 * 4);
-                const int nch = (pt + mc - 1) / mc;
-                if (nch < f_chunks) { f_chunks = nch; f_nt = nt; f_stg = stg; }
-            }
-            const int f_pt = static_cast<int>((s.width + f_nt - 1) / f_nt);
-            const int f_cpt = ((f_pt + f_chunks - 1) / f_chunks + 3) / 4 * 4;
-            const long long f_items = static_cast<long long>(dg.n_groups) * f_chunks;
-            // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
-            // group list) -> glist_s / gcnt[3]: decided on the device, per launch
-            int *glist_f = p->d_glist, *glist_s = p->d_glist + (static_cast<size_t>(p->plan.max_cut) + 64) / 64 * 64;
-            int *gcnt_s = gcnt;                                               // [1] = groups of the grouping-exact kernel
-            if (dg.span_s) {
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
-                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp_s,
-                                   static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
-                                   gcnt + 2);
-                gcnt_s = gcnt + 2;
-            } else {                                                          // both kernels walk the same group list: one pass
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, p->stream, dg.desc, dg.grp,
-                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, glist_s, gcnt);
-            }
-            HIP_TRY(hipGetLastError());
-            f.glist = glist_f; f.gcnt = gcnt;
-            f.chunk_magic = chunk_magic_for(f_chunks);
-            const size_t f_lds_stage = std::max(static_cast<size_t>(lds_row) * sizeof(float), static_cast<size_t>(f_stg) * f_nt * 16);
-            f.slot_off = static_cast<int>(f_lds_stage / sizeof(float));
-            f.chunk_cols = f_cpt * f_nt;
-            f.n_chunks = f_chunks;
-            f.n_groups = dg.n_groups;
-            const int f_grid = static_cast<int>(std::min<long long>(p->n_cus, (f_items + 7) / 8 * 8));
-            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue)
-                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, p->stream, f, dg.desc, dg.grp, queue));
-            a.zero_row = 0;                                                   // the fast launch wrote the "none" row
-            a.glist = glist_s; a.gcnt = gcnt_s;
-        }
-        // ---- the other groups (all of them without certificates): level_split_kernel ----
-        a.slot_off = static_cast<int>(lds_stage_s / sizeof(float));
-        a.chunk_cols = (cpt + 3) / 4 * 4 * nt_s;                        // whole quads of columns per thread
-        a.n_chunks = n_chunks;
-        a.chunk_magic = chunk_magic_for(n_chunks);
-        a.n_groups = dg.n_groups_s;
-        const int grid = static_cast<int>(std::min<long long>(p->n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
-        HIP_TRY(s.pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, p->stream, a, dg.desc, dg.grp_s, queue + 8)
-                          : launch_split<false>(cpt, stg_inst, grid, lds, p->stream, a, dg.desc, dg.grp_s, queue + 8));
+    } else if (s.mode == genphi::kModeFull || s.mode == genphi::kModeSplit) {
+        LaunchRes R;
+        R.stream = p->stream; R.n_cus = p->n_cus; R.tun = &p->tun;
+        R.queue = p->d_queues + 16 * step; R.gcnt = p->d_gcnt + 4 * step;
+        R.glist_f = p->d_glist; R.glist_s = p->d_glist + (static_cast<size_t>(p->plan.max_cut) + 64) / 64 * 64;
+        return launch_rows(R, a, s.mode, s.pos_ord, s.n_prev + 1, s.width, kernel, dg);
     } else {
         return fail(GENPHI_ERR_ARG, "internal: WIDE steps go through launch_wide_level");
     }
     HIP_TRY(hipGetLastError());
     return GENPHI_OK;
+}
+
+// ---- column panels (panel_phi.hip): a level step of a rank's panel through the same row kernels -------------
+const void *genphi::panel_tuning_create() { return new (std::nothrow) Tuning(tuning_from_env()); }
+void genphi::panel_tuning_destroy(const void *t) { delete static_cast<const Tuning *>(t); }
+
+int genphi::launch_panel_level(const PanelLaunch &L)
+{
+    static const Tuning dflt;
+    const Tuning &tun = L.tuning ? *static_cast<const Tuning *>(L.tuning) : dflt;
+    LevelArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.psi = L.psi; a.out = L.out; a.ld_prev = L.ld_prev; a.ld = L.ld; a.width = static_cast<int>(L.ld);
+    a.n_prev = L.n_prev; a.n = L.n_cols; a.zrow = L.n_cut;
+    a.srcA = L.srcA; a.srcB = L.srcB; a.ord = L.ord; a.pk = L.pk_col;
+    a.ord_col = L.ord_col; a.diag_col = L.diag_col; a.pdesc = L.pdesc;
+    a.rows = L.work; a.out_rows = nullptr; a.n_rows = L.n_cut;
+    a.zero_row = 1;
+    a.cert_prev = L.cert_prev; a.cert_out = L.cert_out;
+    a.cert_thresh = cert_threshold(tun);
+    a.cert_fast = (!tun.no_fast && L.cert_prev != nullptr) ? 1 : 0;
+    HIP_TRY(hipMemsetAsync(L.counters, 0, 20 * sizeof(int), L.stream));
+    LaunchRes R;
+    R.stream = L.stream; R.n_cus = L.n_cus; R.tun = &tun;
+    R.queue = L.counters; R.gcnt = L.counters + 16;
+    R.glist_f = L.glist; R.glist_s = L.glist + L.glist_cap;
+    DeviceGroups dg;
+    dg.desc = const_cast<int4 *>(L.desc); dg.grp = const_cast<int2 *>(L.grp); dg.grp_s = dg.grp; dg.span_s = nullptr;
+    dg.n_groups = dg.n_groups_s = L.n_groups;
+    return launch_rows(R, a, L.mode, /*pos_ord=*/false, L.src_width, L.ld, /*kernel=*/0, dg);
 }
 
 // A WIDE level step (see rows_compact_kernel): out = the level matrix of the cut in its
@@ -2283,7 +2459,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
             std::memset(&a, 0, sizeof(a));
             a.psi = psi; a.out = out; a.ld_prev = s.ld_prev; a.ld = s.ld; a.width = static_cast<int>(s.ld); a.n_prev = none; a.n = n;
             a.srcA = d.srcA; a.srcB = d.srcB; a.ord = d.ord; a.rows = d.newrows; a.n_rows = n_new;
-            a.cert_out = cert_out; a.cert_thresh = thr;
+            a.cert_out = cert_out; a.cert_thresh = thr; a.ord_col = d.ord; a.zrow = n;
             dim3 grid(static_cast<unsigned>(n_new), static_cast<unsigned>((s.ld + 255) / 256));
             hipLaunchKernelGGL(level_naive_kernel, grid, dim3(256), 0, p->stream, a);
             HIP_TRY(hipGetLastError());
@@ -2315,7 +2491,7 @@ static int ensure_doubles(double **ptr, size_t *have, size_t need)
 
 // The whole sweep with Float64 level matrices (see level_naive64_kernel): rows [r0, r1) of the
 // proband matrix end up in p->result64 (row pitch = pitch of the last cut).
-static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1)
+static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel)
 {
     const Plan &pl = p->plan;
     const int L = pl.n_levels, n_steps = L - 1;
@@ -2359,13 +2535,24 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1)
         const bool last = s == n_steps - 1;
         double *out = last ? p->result64 : p->buf64[(s + 1) & 1];
         const int rows_n = last ? static_cast<int>(n_rows) : static_cast<int>(st.n);
-        dim3 grid(static_cast<unsigned>(rows_n), static_cast<unsigned>((st.ld + 255) / 256));
-        hipLaunchKernelGGL(level_naive64_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(st.ld_prev),
-                           static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), static_cast<int>(st.n), d.srcA, d.srcB, d.ord,
-                           last ? p->d_perm_rows : static_cast<const int *>(nullptr),
-                           last ? p->d_perm_rows + n_rows : static_cast<const int *>(nullptr),
-                           (last && !pl.final_perm.empty()) ? p->d_final_perm : static_cast<const int *>(nullptr),
-                           static_cast<int>(st.n));
+        const int *k_rows = last ? p->d_perm_rows : static_cast<const int *>(nullptr);
+        const int *k_orows = last ? p->d_perm_rows + n_rows : static_cast<const int *>(nullptr);
+        const int *k_colmap = (last && !pl.final_perm.empty()) ? p->d_final_perm : static_cast<const int *>(nullptr);
+        const int lds_row64 = static_cast<int>((st.n_prev + 1 + 1) / 2 * 2);
+        const size_t lds64 = 2 * static_cast<size_t>(lds_row64) * sizeof(double);
+        if (kernel != 1 && lds64 <= 160 * 1024 && rows_n > 0) {
+            // both Float64 source rows fit in LDS (cuts up to 10,239 members): the row-staged kernel
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full64_kernel), lds64));
+            const int bs = st.n <= 512 ? 64 : (st.n <= 2048 ? 256 : 512);
+            hipLaunchKernelGGL(level_full64_kernel, dim3(static_cast<unsigned>(rows_n)), dim3(bs), lds64, p->stream, psi,
+                               static_cast<long long>(st.ld_prev), static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), d.srcA, d.srcB,
+                               d.ord, k_rows, k_orows, k_colmap, static_cast<int>(st.n), lds_row64);
+        } else {
+            dim3 grid(static_cast<unsigned>(rows_n), static_cast<unsigned>((st.ld + 255) / 256));
+            hipLaunchKernelGGL(level_naive64_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(st.ld_prev),
+                               static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), static_cast<int>(st.n), d.srcA, d.srcB, d.ord,
+                               k_rows, k_orows, k_colmap, static_cast<int>(st.n));
+        }
         HIP_TRY(hipGetLastError());
         if (!last)           // the all-zero "none" row of this level
             HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(double), p->stream));
@@ -2402,7 +2589,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     p->res_f64 = opts && (opts->flags & GENPHI_FLAG_STORAGE_F64);
     if (p->res_f64) {
         p->res_ld = pl.ld[L - 1];
-        return compute_f64(p, r0, r1);
+        return compute_f64(p, r0, r1, kernel);
     }
     rc = ensure_level_buffers(p);
     if (rc) return rc;

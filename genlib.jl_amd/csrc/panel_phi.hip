@@ -21,9 +21,11 @@
 // 4 (n_k^2 + n_{k+1}^2) / W bytes of matrix traffic per rank; a replicated level (what fits one GPU
 // gets) needs no exchange at all, which is why this path is only taken when the matrices do not fit
 // (or when forced: GENPHI_FORCE_EXCHANGE in bench.py, tests).
-// Kernel: one thread per (row, local column), four global gathers, the reference's per-pair
-// arithmetic -- the same device function as level_naive_kernel.  It is the
-// capacity path, not the throughput path.
+// Kernels: a panel holds whole ROWS of its columns, so a level step is the FULL / SPLIT row kernels of
+// genphi_hip.hip (one or two source rows of the rank's extended panel staged in LDS, gathers at the panel
+// columns of the local columns' sources, certified grouping-free bodies) run over the rank's local columns:
+// launch_panel_level (panel_launch.h).  Panel rows too long for LDS (> 36,864 floats) and GENPHI_PANEL_NAIVE
+// fall back to one thread per (row, local column) with four global gathers (panel_level_kernel).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,6 +37,7 @@
 #include <vector>
 
 #include "../../include/genphi.h"
+#include "panel_launch.h"
 #include "planner.h"
 
 int genphi_set_error(int code, const std::string &msg);      // genphi_hip.hip
@@ -98,8 +101,10 @@ panel_pack_kernel(const float *__restrict__ panel, long long ldp, int n_rows, co
 }
 
 // panel[i][col0 + k] = recv[k][i] (the received columns become extension columns)
+// (a received value in (0, 2^-27) voids the exactness certificate of the row it lands in: cert[i] = 1)
 __global__ void __launch_bounds__(256)
-panel_unpack_kernel(float *__restrict__ panel, long long ldp, int n_rows, int col0, int n_recv, const float *__restrict__ recv)
+panel_unpack_kernel(float *__restrict__ panel, long long ldp, int n_rows, int col0, int n_recv, const float *__restrict__ recv,
+                    int *__restrict__ cert, unsigned cert_thresh)
 {
     __shared__ float tile[64][65];
     const int k0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
@@ -111,7 +116,11 @@ panel_unpack_kernel(float *__restrict__ panel, long long ldp, int n_rows, int co
     __syncthreads();
     for (int q = ty; q < 64; q += 4) {
         const int i = i0 + q, k = k0 + tx;
-        if (i < n_rows && k < n_recv) panel[(long long)i * ldp + col0 + k] = tile[tx][q];
+        if (i < n_rows && k < n_recv) {
+            const float v = tile[tx][q];
+            panel[(long long)i * ldp + col0 + k] = v;
+            if (cert && __float_as_uint(v) - 1u < cert_thresh) cert[i] = 1;
+        }
     }
 }
 
@@ -143,6 +152,23 @@ struct PanelStep {
     // the step itself
     std::vector<int4> col;                     // per local column of the new cut
     int n_cols = 0;
+    // row-kernel form of the step (launch_panel_level)
+    int mode = 2;                              // 0 FULL, 1 SPLIT, 2 per-entry kernel
+    int src_width = 0;                         // floats of a source panel row incl. its zero column
+    std::vector<unsigned> pk_col;              // panel column of A | of B << 16, per local column (+ padding)
+    std::vector<int> ord_col;                  // rank word per local column (+ padding)
+    std::vector<int> diag_col;                 // per row of the cut: its local column or -1
+    std::vector<int> work;                     // rows sorted by (A source, B source)
+    std::vector<int4> desc;                    // SPLIT
+    std::vector<int2> grp, pdesc;
+    int n_groups = 0;
+};
+
+struct DevPanelStep {
+    unsigned *pk_col = nullptr;
+    int *ord_col = nullptr, *diag_col = nullptr, *work = nullptr;
+    int4 *desc = nullptr;
+    int2 *grp = nullptr, *pdesc = nullptr;
 };
 
 }  // namespace
@@ -164,6 +190,12 @@ struct genphi_panel {
     float *result = nullptr;
     std::vector<int *> d_srcA, d_srcB, d_ord, d_send_cols, d_member;
     std::vector<int4 *> d_col;
+    std::vector<DevPanelStep> d_step;
+    int *d_cert[2] = {nullptr, nullptr};       // exactness certificates of the rows of panel[0] / panel[1]
+    int *d_counters = nullptr, *d_glist = nullptr;
+    int glist_cap = 0, n_cus = 256;
+    const void *tuning = nullptr;              // environment hooks (panel_tuning_create)
+    bool naive = false;                        // GENPHI_PANEL_NAIVE: per-entry kernel on every step (A/B, tests)
     int cur = 0;                               // panel[cur] holds the level of the last step computed
 };
 
@@ -174,6 +206,9 @@ static void panel_free_device(genphi_panel *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     auto rel = [](auto *&q) { if (q) (void)hipFree(q); q = nullptr; };
     rel(p->panel[0]); rel(p->panel[1]); rel(p->result);
+    rel(p->d_cert[0]); rel(p->d_cert[1]); rel(p->d_counters); rel(p->d_glist);
+    for (DevPanelStep &d : p->d_step) { rel(d.pk_col); rel(d.ord_col); rel(d.diag_col); rel(d.work); rel(d.desc); rel(d.grp); rel(d.pdesc); }
+    p->d_step.clear();
     p->panel_floats[0] = p->panel_floats[1] = 0;
     for (auto &v : {&p->d_srcA, &p->d_srcB, &p->d_ord, &p->d_send_cols, &p->d_member}) { for (int *&q : *v) rel(q); v->clear(); }
     for (int4 *&q : p->d_col) rel(q);
@@ -209,6 +244,8 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
     if (rc) { delete p; return genphi_set_error(rc, err); }
     p->rank = rank; p->world = world;
     if (const char *e = std::getenv("GENPHI_TEST_FAIL_ALLOC")) p->fail_alloc_at = std::atoi(e);
+    p->naive = std::getenv("GENPHI_PANEL_NAIVE") != nullptr;
+    p->tuning = genphi::panel_tuning_create();
     const genphi::Plan &pl = p->plan;
     const int L = pl.n_levels;
     const int64_t N = pl.n_pro;
@@ -295,6 +332,46 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
             // a dragged column: source = itself (local), B = none, weight 1 (st.srcB is none already)
             ps.col[jl] = make_int4(ext_of[st.srcA[j]], ext_of[st.srcB[j]], j, st.ord[j]);
         }
+        // ---- the same step for the row kernels: a source "row" is a row of the extended panel (zcol + 1 floats) ----
+        ps.src_width = zcol + 1;
+        int lds_cap = genphi::kPanelSplitMaxFloats, full_max = genphi::kPanelFullMaxFloats;
+        if (const char *e = std::getenv("GENPHI_LDS_CAP_FLOATS")) { const int v = std::atoi(e); if (v >= 16) lds_cap = v; }        // test hooks, as for plans
+        if (const char *e = std::getenv("GENPHI_FULL_MAX_FLOATS")) { const int v = std::atoi(e); if (v >= 0) full_max = v; }
+        const int row4 = (ps.src_width + 3) / 4 * 4;
+        ps.mode = p->naive ? 2 : (2 * row4 <= lds_cap && row4 <= full_max ? 0 : (row4 <= lds_cap && zcol < 65536 ? 1 : 2));
+        if (ps.mode != 2) {
+            const size_t nc = static_cast<size_t>(ps.n_cols);
+            ps.pk_col.assign(nc + genphi::kPanelIdxPad, static_cast<unsigned>(zcol) | (static_cast<unsigned>(zcol) << 16));
+            ps.ord_col.assign(nc + genphi::kPanelIdxPad, 0);
+            ps.diag_col.assign(st.n, -1);
+            for (int jl = 0; jl < ps.n_cols; ++jl) {
+                const int4 cj = ps.col[jl];
+                // a dragged column is stored as A = B = itself, so that EVERY column has weight 1/2 (as in the plan's pk words)
+                const bool dragged_col = cj.w >= 0;
+                ps.pk_col[jl] = static_cast<unsigned>(cj.x) | (static_cast<unsigned>(dragged_col ? cj.x : cj.y) << 16);
+                ps.ord_col[jl] = cj.w;
+                ps.diag_col[cj.z] = jl;
+            }
+            ps.work.resize(st.n);
+            for (int64_t k = 0; k < st.n; ++k) ps.work[k] = static_cast<int>(k);
+            std::stable_sort(ps.work.begin(), ps.work.end(), [&](int x, int y) {
+                return st.srcA[x] != st.srcA[y] ? st.srcA[x] < st.srcA[y] : st.srcB[x] < st.srcB[y];     // "no B" = n_prev sorts last
+            });
+            if (ps.mode == 1) {
+                // sibling groups: runs of equal A source, at most 4 children (the grouping-exact kernel keeps one rank mask per child)
+                ps.desc.resize(st.n); ps.pdesc.resize(st.n);
+                int lastA = -1;
+                for (int w = 0; w < static_cast<int>(st.n); ++w) {
+                    const int i = ps.work[w];
+                    ps.desc[w] = make_int4(i, i, st.srcB[i], st.ord[i]);
+                    const int dcol = ps.diag_col[i];
+                    ps.pdesc[w] = make_int2(dcol, dcol >= 0 ? static_cast<int>(ps.pk_col[dcol] & 0xffff) : zcol);
+                    if (w == 0 || st.srcA[i] != lastA || w - ps.grp.back().x >= 4) { ps.grp.push_back(make_int2(w, st.srcA[i])); lastA = st.srcA[i]; }
+                }
+                ps.n_groups = static_cast<int>(ps.grp.size());
+                ps.grp.push_back(make_int2(static_cast<int>(st.n), 0));
+            }
+        }
     }
     *out = p;
     return GENPHI_OK;
@@ -302,6 +379,10 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
 
 int64_t genphi_panel_n_steps(const genphi_panel *p) { return p ? std::max(p->plan.n_levels - 1, 0) : -1; }
 int64_t genphi_panel_n_probands(const genphi_panel *p) { return p ? p->plan.n_pro : -1; }
+int genphi_panel_step_mode(const genphi_panel *p, int32_t step)
+{
+    return (!p || step < 0 || step >= static_cast<int32_t>(p->steps.size())) ? -1 : p->steps[step].mode;
+}
 
 int genphi_panel_result_rows(const genphi_panel *p, int64_t *row_begin, int64_t *n_rows)
 {
@@ -322,7 +403,8 @@ int genphi_panel_exchange_counts(const genphi_panel *p, int32_t step, int64_t *s
     return GENPHI_OK;
 }
 
-/* Bytes of device memory this rank's two panels need (the size test of the host driver). */
+/* Bytes of device memory this rank needs: its two panels (with their tail padding), its row block of the
+ * result, the per-step index arrays and the certificates (the size test of the host driver). */
 double genphi_panel_device_bytes(const genphi_panel *p)
 {
     if (!p) return 0.0;
@@ -333,7 +415,16 @@ double genphi_panel_device_bytes(const genphi_panel *p)
         const double f = static_cast<double>(p->plan.cut_sizes[c] + 1) * static_cast<double>(pitch(static_cast<long long>(p->member[c].size()) + ext));
         need[c & 1] = std::max(need[c & 1], f);
     }
-    return 4.0 * (need[0] + need[1]);
+    double bytes = 4.0 * (need[0] + need[1] + 2.0 * 64 * 1024);
+    bytes += 4.0 * static_cast<double>(p->n_rows_res) * static_cast<double>(pitch(p->plan.n_pro));            // result row block
+    bytes += 2.0 * 4.0 * static_cast<double>(p->plan.max_cut + 1) + 8.0 * static_cast<double>((p->plan.max_cut + 64) / 64 * 64);   // certificates, group lists
+    for (int c = 0; c + 1 < L; ++c) {
+        const PanelStep &ps = p->steps[c];
+        bytes += 12.0 * static_cast<double>(p->plan.steps[c].n) + 4.0 * static_cast<double>(ps.send_cols.size()) + 16.0 * static_cast<double>(ps.col.size());
+        bytes += 4.0 * static_cast<double>(ps.pk_col.size() + ps.ord_col.size() + ps.diag_col.size() + ps.work.size()) +
+                 16.0 * static_cast<double>(ps.desc.size()) + 8.0 * static_cast<double>(ps.grp.size() + ps.pdesc.size());
+    }
+    return bytes;
 }
 
 static int panel_upload_impl(genphi_panel *p, int device)
@@ -360,7 +451,9 @@ static int panel_upload_impl(genphi_panel *p, int device)
     }
     for (int b = 0; b < 2; ++b) {
         if (!need[b]) continue;
+        need[b] += 64 * 1024;                               // zeroed tail: the SPLIT kernels stage whole float4 batches past the last row
         PN_TRY(pmalloc(reinterpret_cast<void **>(&p->panel[b]), need[b] * sizeof(float)));
+        PN_TRY(hipMemset(p->panel[b], 0, need[b] * sizeof(float)));
         p->panel_floats[b] = need[b];
     }
     auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
@@ -381,6 +474,30 @@ static int panel_upload_impl(genphi_panel *p, int device)
     }
     for (int c = 0; c < L; ++c)
         PN_TRY(up(p->member[c].data(), p->member[c].size() * sizeof(int), reinterpret_cast<void **>(&p->d_member[c])));
+    {
+        hipDeviceProp_t prop;
+        PN_TRY(hipGetDeviceProperties(&prop, device));
+        p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
+    }
+    p->glist_cap = static_cast<int>((pl.max_cut + 64) / 64 * 64);
+    for (int b = 0; b < 2; ++b) PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_cert[b]), (static_cast<size_t>(pl.max_cut) + 1) * sizeof(int)));
+    PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_counters), 20 * sizeof(int)));
+    PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_glist), 2 * static_cast<size_t>(p->glist_cap) * sizeof(int)));
+    p->d_step.assign(S, DevPanelStep());
+    for (size_t s = 0; s < S; ++s) {
+        const PanelStep &ps = p->steps[s];
+        DevPanelStep &d = p->d_step[s];
+        if (ps.mode == 2) continue;
+        PN_TRY(up(ps.pk_col.data(), ps.pk_col.size() * sizeof(unsigned), reinterpret_cast<void **>(&d.pk_col)));
+        PN_TRY(up(ps.ord_col.data(), ps.ord_col.size() * sizeof(int), reinterpret_cast<void **>(&d.ord_col)));
+        PN_TRY(up(ps.diag_col.data(), ps.diag_col.size() * sizeof(int), reinterpret_cast<void **>(&d.diag_col)));
+        PN_TRY(up(ps.work.data(), ps.work.size() * sizeof(int), reinterpret_cast<void **>(&d.work)));
+        if (ps.mode == 1) {
+            PN_TRY(up(ps.desc.data(), ps.desc.size() * sizeof(int4), reinterpret_cast<void **>(&d.desc)));
+            PN_TRY(up(ps.grp.data(), ps.grp.size() * sizeof(int2), reinterpret_cast<void **>(&d.grp)));
+            PN_TRY(up(ps.pdesc.data(), ps.pdesc.size() * sizeof(int2), reinterpret_cast<void **>(&d.pdesc)));
+        }
+    }
     return GENPHI_OK;
 }
 
@@ -418,6 +535,7 @@ int genphi_panel_begin(genphi_panel *p, int32_t device)
         hipLaunchKernelGGL(panel_identity_kernel, dim3((nc + 255) / 256), dim3(256), 0, p->stream, p->panel[0], ld, n0, p->d_member[0], nc);
         PN_TRY(hipGetLastError());
     }
+    PN_TRY(hipMemsetAsync(p->d_cert[0], 0, (static_cast<size_t>(pl.max_cut) + 1) * sizeof(int), p->stream));   // 1/2 I: every row certified
     p->cur = 0;
     PN_TRY(hipStreamSynchronize(p->stream));
     return GENPHI_OK;
@@ -456,17 +574,39 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
     if (ps.n_ext > 0) {
         if (!d_recv) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_compute: d_recv is NULL");
         dim3 grid(static_cast<unsigned>((ps.n_ext + 63) / 64), static_cast<unsigned>((n_prev + 63) / 64));
-        hipLaunchKernelGGL(panel_unpack_kernel, grid, dim3(256), 0, p->stream, psi, ldp, n_prev, n_own, ps.n_ext, d_recv);
+        hipLaunchKernelGGL(panel_unpack_kernel, grid, dim3(256), 0, p->stream, psi, ldp, n_prev, n_own, ps.n_ext, d_recv,
+                           p->d_cert[step & 1], (static_cast<unsigned>(127 - 27) << 23) - 1u);
         PN_TRY(hipGetLastError());
     }
     const bool last = step + 1 == static_cast<int32_t>(p->steps.size());
     const long long ext_next = last ? 0 : p->steps[step + 1].n_ext;
     const long long ldo = pitch(static_cast<long long>(ps.n_cols) + ext_next);
     float *out = p->panel[(step + 1) & 1];
-    dim3 grid(static_cast<unsigned>(n + 1), static_cast<unsigned>(std::min<long long>((ldo + 255) / 256, 64)));
-    hipLaunchKernelGGL(panel_level_kernel, grid, dim3(256), 0, p->stream, psi, ldp, n_prev, out, ldo, n, p->d_srcA[step], p->d_srcB[step],
-                       p->d_ord[step], p->d_col[step], ps.n_cols);
-    PN_TRY(hipGetLastError());
+    int *cert_out = p->d_cert[(step + 1) & 1];
+    PN_TRY(hipMemsetAsync(cert_out, 0, (static_cast<size_t>(n) + 1) * sizeof(int), p->stream));
+    if (ps.mode != 2) {
+        // the FULL / SPLIT row kernels over this rank's local columns (panel_launch.h)
+        const DevPanelStep &d = p->d_step[step];
+        genphi::PanelLaunch L;
+        L.stream = p->stream; L.n_cus = p->n_cus; L.tuning = p->tuning;
+        L.psi = psi; L.out = out; L.ld_prev = ldp; L.ld = ldo;
+        L.n_prev = n_prev; L.n_cut = n; L.n_cols = ps.n_cols; L.src_width = ps.src_width;
+        L.srcA = p->d_srcA[step]; L.srcB = p->d_srcB[step]; L.ord = p->d_ord[step];
+        L.pk_col = d.pk_col; L.ord_col = d.ord_col; L.diag_col = d.diag_col; L.work = d.work;
+        L.mode = ps.mode; L.desc = d.desc; L.grp = d.grp; L.pdesc = d.pdesc; L.n_groups = ps.n_groups;
+        L.cert_prev = p->d_cert[step & 1]; L.cert_out = cert_out;
+        L.counters = p->d_counters; L.glist = p->d_glist; L.glist_cap = p->glist_cap;
+        const int rc = genphi::launch_panel_level(L);
+        if (rc) return rc;
+    } else {
+        // panel rows too long for LDS: one thread per (row, local column); every row of the new panel counts as
+        // uncertified (the kernel does not track small values), which only selects the grouping-exact bodies later
+        dim3 grid(static_cast<unsigned>(n + 1), static_cast<unsigned>(std::min<long long>((ldo + 255) / 256, 64)));
+        hipLaunchKernelGGL(panel_level_kernel, grid, dim3(256), 0, p->stream, psi, ldp, n_prev, out, ldo, n, p->d_srcA[step], p->d_srcB[step],
+                           p->d_ord[step], p->d_col[step], ps.n_cols);
+        PN_TRY(hipGetLastError());
+        PN_TRY(hipMemsetAsync(cert_out, 0xff, static_cast<size_t>(n) * sizeof(int), p->stream));
+    }
     PN_TRY(hipStreamSynchronize(p->stream));
     p->cur = (step + 1) & 1;
     return GENPHI_OK;
@@ -502,6 +642,7 @@ void genphi_panel_destroy(genphi_panel *p)
 {
     if (!p) return;
     panel_free_device(p);
+    genphi::panel_tuning_destroy(p->tuning);
     delete p;
 }
 

@@ -89,6 +89,7 @@ def phi_panels(pedigree, probandIDs, dist=None, device=None, stats=None):
         if stats is not None:
             stats["exchange_bytes_sent"] = sent
             stats["panel_device_bytes"] = pl.device_bytes
+            stats["step_modes"] = pl.step_modes()
         r0, _ = pl.result_rows()
         return pl.result_to_host(), r0
     finally:

@@ -220,12 +220,15 @@ void genphi_sparse_destroy(genphi_sparse *h);
  *   create            plan + ownership + exchange lists (host only; identical arguments on every rank)
  *   begin             upload, Psi_1 = 1/2 I on the local columns
  *   exchange_counts   columns to send to / receive from every rank before step `step`, floats per column
- *   pack / compute    fill the send buffer; unpack the received columns and run the level step
+ *   pack / compute    fill the send buffer; unpack the received columns and run the level step: the FULL / SPLIT
+ *                     row kernels of the dense path on this rank's local columns (source rows = rows of the
+ *                     rank's extended panel), the per-entry kernel when a panel row does not fit in LDS
  *   result_to_host    this rank's row block [row_begin, row_begin + n_rows) of Phi (proband order)      */
 typedef struct genphi_panel genphi_panel;
 int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
                         int64_t n_pro, const int64_t *pro_ids, int32_t rank, int32_t world, genphi_panel **out);
 int64_t genphi_panel_n_steps(const genphi_panel *p);
+int genphi_panel_step_mode(const genphi_panel *p, int32_t step);   /* 0 FULL / 1 SPLIT row kernels on the local columns, 2 per-entry kernel; -1 bad argument */
 int64_t genphi_panel_n_probands(const genphi_panel *p);
 int genphi_panel_result_rows(const genphi_panel *p, int64_t *row_begin, int64_t *n_rows);
 int genphi_panel_exchange_counts(const genphi_panel *p, int32_t step, int64_t *send_cols, int64_t *recv_cols, int64_t *col_floats);

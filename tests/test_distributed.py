@@ -120,8 +120,9 @@ def test_panel_mode_matches_the_oracle(nproc):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     d = json.loads(lines[-1])
-    assert d["ok"] and d["world"] == nproc
+    assert d["ok"] and d["world"] == nproc, d
     assert (d["exchange_bytes_sent_rank0"] > 0) == (nproc > 1)
+    assert d["modes_seen"] == [0, 1, 2]          # FULL and SPLIT row kernels on the panel's columns, and the per-entry fallback
 
 
 @pytest.mark.gpu
