@@ -46,8 +46,8 @@ EXPORTED_SYMBOLS = [
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
-    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
-    "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
+    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
+    "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_step_ms", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
     "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_result_to_host",
     "genphi_panel_destroy",
 ]
@@ -115,6 +115,9 @@ def lib():
         L.genphi_sparse_phi.restype = C.c_int
         L.genphi_sparse_info.argtypes = [C.c_void_p, _I64P, _I64P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.genphi_sparse_info.restype = C.c_int
+        L.genphi_sparse_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), _I64P, _F32P,
+                                          C.POINTER(C.c_double), C.c_int32]
+        L.genphi_sparse_stats.restype = C.c_int
         L.genphi_sparse_get.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double)]
         L.genphi_sparse_get.restype = C.c_int
         L.genphi_sparse_entries.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, _F32P]
@@ -125,6 +128,8 @@ def lib():
         L.genphi_panel_create.restype = C.c_int
         L.genphi_panel_n_steps.argtypes = [C.c_void_p]
         L.genphi_panel_n_steps.restype = C.c_int64
+        L.genphi_panel_step_ms.argtypes = [C.c_void_p, C.c_int32]
+        L.genphi_panel_step_ms.restype = C.c_double
         L.genphi_panel_step_mode.argtypes = [C.c_void_p, C.c_int32]
         L.genphi_panel_step_mode.restype = C.c_int
         L.genphi_panel_n_probands.argtypes = [C.c_void_p]
@@ -401,6 +406,17 @@ class KinshipMatrix:
             _raise(rc)
         return nr.value, nz.value, sa.value, sd.value
 
+    def stats(self):
+        """Measurement of the GPU sweep that built this matrix: dict(n_waves, sweep_ms, algorithmic_bytes, max_active,
+        wave_ms, wave_bytes) -- device time from HIP events, bytes = 4 (n_old^2 + n_next^2) per wave."""
+        nw, ms, ab, ma = C.c_int32(), C.c_double(), C.c_double(), C.c_int64()
+        rc = lib().genphi_sparse_stats(self._h, C.byref(nw), C.byref(ms), C.byref(ab), C.byref(ma), None, None, 0)
+        if rc:
+            _raise(rc)
+        wm, wb = np.zeros(nw.value, np.float32), np.zeros(nw.value, np.float64)
+        lib().genphi_sparse_stats(self._h, None, None, None, None, wm.ctypes.data_as(_F32P), wb.ctypes.data_as(C.POINTER(C.c_double)), nw.value)
+        return {"n_waves": nw.value, "sweep_ms": ms.value, "algorithmic_bytes": ab.value, "max_active": ma.value, "wave_ms": wm, "wave_bytes": wb}
+
     def get(self, id1, id2):
         id1, id2 = _i64(np.atleast_1d(id1)), _i64(np.atleast_1d(id2))
         out = np.empty(len(id1), dtype=np.float64)
@@ -472,6 +488,10 @@ class PanelPlan:
         """Kernel family of every level step on this rank's panel: 0 FULL, 1 SPLIT (the row kernels of the
         dense path on the local columns), 2 per-entry kernel (panel rows too long for LDS, or GENPHI_PANEL_NAIVE)."""
         return [int(lib().genphi_panel_step_mode(self._h, k)) for k in range(self.n_steps)]
+
+    def step_ms(self):
+        """Device time (ms) of every level step's kernels in the last sweep (unpack of the received columns + level kernel)."""
+        return [float(lib().genphi_panel_step_ms(self._h, k)) for k in range(self.n_steps)]
 
     def exchange_counts(self, step):
         """(columns to send per rank, columns to receive per rank, floats per column) before level step `step`."""

@@ -196,6 +196,8 @@ struct genphi_panel {
     int glist_cap = 0, n_cus = 256;
     const void *tuning = nullptr;              // environment hooks (panel_tuning_create)
     bool naive = false;                        // GENPHI_PANEL_NAIVE: per-entry kernel on every step (A/B, tests)
+    hipEvent_t ev[2] = {nullptr, nullptr};     // around the kernels of the last genphi_panel_compute
+    std::vector<float> step_ms;                // device time of every step's kernels (unpack + level) in the last sweep
     int cur = 0;                               // panel[cur] holds the level of the last step computed
 };
 
@@ -207,6 +209,7 @@ static void panel_free_device(genphi_panel *p)
     auto rel = [](auto *&q) { if (q) (void)hipFree(q); q = nullptr; };
     rel(p->panel[0]); rel(p->panel[1]); rel(p->result);
     rel(p->d_cert[0]); rel(p->d_cert[1]); rel(p->d_counters); rel(p->d_glist);
+    for (hipEvent_t &e : p->ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (DevPanelStep &d : p->d_step) { rel(d.pk_col); rel(d.ord_col); rel(d.diag_col); rel(d.work); rel(d.desc); rel(d.grp); rel(d.pdesc); }
     p->d_step.clear();
     p->panel_floats[0] = p->panel_floats[1] = 0;
@@ -379,6 +382,11 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
 
 int64_t genphi_panel_n_steps(const genphi_panel *p) { return p ? std::max(p->plan.n_levels - 1, 0) : -1; }
 int64_t genphi_panel_n_probands(const genphi_panel *p) { return p ? p->plan.n_pro : -1; }
+/* device time (ms, HIP events) of the kernels of level step `step` in the last sweep: unpack of the received columns + the level kernel */
+double genphi_panel_step_ms(const genphi_panel *p, int32_t step)
+{
+    return (!p || step < 0 || step >= static_cast<int32_t>(p->step_ms.size())) ? -1.0 : static_cast<double>(p->step_ms[step]);
+}
 int genphi_panel_step_mode(const genphi_panel *p, int32_t step)
 {
     return (!p || step < 0 || step >= static_cast<int32_t>(p->steps.size())) ? -1 : p->steps[step].mode;
@@ -480,6 +488,8 @@ static int panel_upload_impl(genphi_panel *p, int device)
         p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
     }
     p->glist_cap = static_cast<int>((pl.max_cut + 64) / 64 * 64);
+    for (hipEvent_t &e : p->ev) PN_TRY(hipEventCreate(&e));
+    p->step_ms.assign(S, 0.f);
     for (int b = 0; b < 2; ++b) PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_cert[b]), (static_cast<size_t>(pl.max_cut) + 1) * sizeof(int)));
     PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_counters), 20 * sizeof(int)));
     PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_glist), 2 * static_cast<size_t>(p->glist_cap) * sizeof(int)));
@@ -571,6 +581,7 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
     const int n_own = static_cast<int>(p->member[step].size());
     const long long ldp = pitch(static_cast<long long>(n_own) + ps.n_ext);
     float *psi = p->panel[step & 1];
+    PN_TRY(hipEventRecord(p->ev[0], p->stream));
     if (ps.n_ext > 0) {
         if (!d_recv) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_compute: d_recv is NULL");
         dim3 grid(static_cast<unsigned>((ps.n_ext + 63) / 64), static_cast<unsigned>((n_prev + 63) / 64));
@@ -607,7 +618,9 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
         PN_TRY(hipGetLastError());
         PN_TRY(hipMemsetAsync(cert_out, 0xff, static_cast<size_t>(n) * sizeof(int), p->stream));
     }
+    PN_TRY(hipEventRecord(p->ev[1], p->stream));
     PN_TRY(hipStreamSynchronize(p->stream));
+    PN_TRY(hipEventElapsedTime(&p->step_ms[step], p->ev[0], p->ev[1]));
     p->cur = (step + 1) & 1;
     return GENPHI_OK;
 }

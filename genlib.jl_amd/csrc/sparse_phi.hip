@@ -8,25 +8,39 @@
 // earlier individual as RN32(phi[father, j]/2 + phi[mother, j]/2) (Float64 sum of two Float32
 // halves, one Float32 store), and a non-proband parent is dropped once all its children are done.
 // Values are stored under (rank of the earlier processed, rank of the later processed) but looked
-// up under (smaller rank, larger rank): whenever two individuals of equal depth leave the queue in
-// the opposite order of their ranks, their kinship is stored where no lookup finds it -- it reads
-// as 0 from then on (tests/oracle restate that behaviour; this file reproduces it, it does not
-// "fix" it).
+// up under (smaller rank, larger rank): whenever two individuals leave the queue in the opposite
+// order of their ranks, their kinship is stored where no lookup finds it -- it reads as 0 from then
+// on (tests/oracle restate that behaviour; this file reproduces it, it does not "fix" it).  With
+// genealogy(...; sort=true) that only happens inside one depth; with sort=false (rank = file
+// position) it happens across depths too.
 //
 // Design here (not a translation): the queue order is depth-sorted (a child is enqueued while its
-// deepest parent is processed) WHATEVER the ranks are (with genealogy(...; sort=false) the rank is the
-// file position and need not follow the depth), so all individuals of one depth -- a WAVE -- only
-// need kinships with strictly older individuals and with each other through those:
-//   T[i][q]  = RN32(L(f_i, q)/2 + L(m_i, q)/2)      new i x every live older q   (one kernel)
+// deepest parent is processed) WHATEVER the ranks are, so all individuals of one depth -- a WAVE --
+// only need kinships with strictly older individuals and with each other through those:
+//   T[i][q]  = RN32(L(f_i, q)/2 + L(m_i, q)/2)      new i x every live older q
 //   S[i][j]  = RN32(L'(j, f_i)/2 + L'(j, m_i)/2)    new i x new j, j processed before i, where
 //              L'(j, p) = T[j][p] if rank(p) < rank(j) (p left the queue before j), else 0
 //   S[i][i]  = RN32(1/2 + L(f_i, m_i)/2)
 // with L(a, b) = the stored value if the (earlier, later) key equals the (smaller rank, larger rank)
 // key, else 0 (src/compute.jl:366-390 looks up phi[min rank][max rank], :392-394 stores under
-// [rank of the live one][rank of the new one]).  The live set is a dense matrix in HBM ("active matrix"), compacted after every wave
-// (retired parents leave), exactly like the cuts of the dense path with other membership rules.
-// The host simulates the queue once (integers only) to get the processing order, the waves and the
-// wave after which every individual retires; all kinship arithmetic runs in the kernels below.
+// [rank of the live one][rank of the new one]).  The live set is a dense matrix in HBM ("active
+// matrix"), rebuilt after every wave as [survivors..., new...] (retired parents leave), like the cuts
+// of the dense path with other membership rules.  Per wave, all streaming, no host round trip:
+//   sparse_rows_kernel     the new rows against the old members: the two parent rows of the active matrix
+//                          streamed with 16-byte loads, masked by the key rule, written twice -- whole
+//                          (T, for the new x new block) and compacted into the next matrix (new x survivors)
+//   sparse_compact_kernel  survivors x survivors: a stream compaction of the old matrix
+//   sparse_newnew_kernel   new x new, upper triangle in queue order: row j of T staged in LDS, two gathers
+//                          per entry; the self kinships
+//   sparse_mirror_kernel   survivors x new and the lower triangle by 64 x 64 tile transposition
+// The host simulates the queue once (integers only: processing order, waves, the wave after which
+// every individual retires) and uploads every wave's index arrays in ONE blob before the sweep; the
+// sweep is one stream of launches with a single synchronisation at its end.
+//
+// Entries that outlive their column (src/compute.jl:401-430 deletes phi[rank_j][parent] only for
+// rank_j < parent rank): a proband j that left the queue before a non-proband x and has the larger rank
+// keeps phi[rank_j][rank_x] for good -- `show` counts it, phiMean sums it.  The kernel that computes such
+// an entry appends it (when > 0) to a list through an atomic counter.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,93 +61,175 @@ namespace {
 // "half" as the reference computes it: Float32 / 2 in Float32 (exact unless the result is subnormal)
 __device__ __forceinline__ float half32(float v) { return v / 2.0f; }
 
-// stored value of the pair of active slots (a, b), as a lookup sees it (see L above); M is the
-// active matrix (pitch ld), meta[s] = (rank, processing index) of slot s; none = zero row / column
-// meta = (rank, processing index): does a lookup find the kinship of two distinct individuals?
+// meta = (2 * rank + is_proband, processing index).  Distinct individuals have distinct ranks, so the
+// order of the first words is the order of the ranks.  Does a lookup find the kinship of two DISTINCT
+// individuals?  Only if the earlier processed one has the smaller rank.
 __device__ __forceinline__ bool key_found(int2 ma, int2 mb) { return (ma.y < mb.y) == (ma.x < mb.x); }
 
-__device__ __forceinline__ float lookup(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int a, int b, int none)
+struct StaleOut {            // entries that outlive their column: (row rank, column rank, value) appended through cnt
+    int *cnt;
+    int cap;
+    int2 *rc;
+    float *val;
+};
+
+__device__ __forceinline__ void stale_append(const StaleOut &so, int row_rank, int col_rank, float v)
 {
-    if (a == none || b == none) return 0.f;
-    if (a != b && !key_found(meta[a], meta[b])) return 0.f;     // stored under a key no lookup uses
-    return M[(long long)a * ld + b];
+    const int k = atomicAdd(so.cnt, 1);
+    if (k < so.cap) { so.rc[k] = make_int2(row_rank, col_rank); so.val[k] = v; }
 }
 
-// T[i][q] for the wave's new individuals i and every live slot q (q == n_old: the zero column)
+// New rows against the old members.  par[i] = (father slot, mother slot, 2 rank + pro of the father, of the
+// mother) of new individual i (slot n_old = none); newpos[q] = column of old slot q in the next matrix or -1.
+//   T[i][q]                     = RN32(L(f_i, q)/2 + L(m_i, q)/2)   for every old q
+//   next[n_surv + i][newpos[q]] = the same, where q survives
+// Four consecutive old slots per thread: 16-byte loads of the parent rows and of the index words.  Rows of M
+// and T are padded to a multiple of 64 floats and every index array to 256 bytes, so the quads need no clamp.
 __global__ void __launch_bounds__(256)
-sparse_new_old_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old,
-                      const int2 *__restrict__ par, float *__restrict__ T, long long ldT)
+sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                   const int2 *__restrict__ meta_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
+                   float *__restrict__ next, long long ld_next, int n_surv, StaleOut so)
 {
     const int i = blockIdx.x;
-    const int2 p = par[i];                                       // (father slot, mother slot), n_old = none
-    for (int q = blockIdx.y * 256 + threadIdx.x; q < ldT; q += gridDim.y * 256) {
-        float v = 0.f;
-        if (q < n_old) {
-            const double c = 0.0 + static_cast<double>(half32(lookup(M, ld, meta, p.x, q, n_old))) +
-                             static_cast<double>(half32(lookup(M, ld, meta, p.y, q, n_old)));
-            v = static_cast<float>(c);
-        }
-        T[(long long)i * ldT + q] = v;
+    const int4 p = par[i];
+    const bool hasF = p.x != n_old, hasM = p.y != n_old;             // workgroup-uniform
+    const int2 mf = hasF ? meta[p.x] : make_int2(0, 0), mm = hasM ? meta[p.y] : make_int2(0, 0);
+    const int2 mi = meta_new[i];
+    float *trow = T + (long long)i * ldT;
+    float *orow = next + (long long)(n_surv + i) * ld_next;
+    const int q0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (q0 >= n_old) return;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a4 = hasF ? *reinterpret_cast<const float4 *>(M + (long long)p.x * ld + q0) : z4;
+    const float4 b4 = hasM ? *reinterpret_cast<const float4 *>(M + (long long)p.y * ld + q0) : z4;
+    const int4 m01 = *reinterpret_cast<const int4 *>(meta + q0), m23 = *reinterpret_cast<const int4 *>(meta + q0 + 2);
+    const int4 np4 = *reinterpret_cast<const int4 *>(newpos + q0);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    const int2 mq[4] = {make_int2(m01.x, m01.y), make_int2(m01.z, m01.w), make_int2(m23.x, m23.y), make_int2(m23.z, m23.w)};
+    const int np[4] = {np4.x, np4.y, np4.z, np4.w};
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        // L(parent, q): the self entry of the parent is always found, any other only under the key rule
+        const float lf = (hasF && (q == p.x || key_found(mf, mq[u]))) ? a[u] : 0.f;
+        const float lm = (hasM && (q == p.y || key_found(mm, mq[u]))) ? b[u] : 0.f;
+        v[u] = q < n_old ? static_cast<float>(0.0 + static_cast<double>(half32(lf)) + static_cast<double>(half32(lm))) : 0.f;
+    }
+    *reinterpret_cast<float4 *>(trow + q0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (q0 + u >= n_old) break;
+        if (np[u] >= 0) orow[np[u]] = v[u];
+        // phi[rank_q][rank_i] outlives i's retirement when q is a proband with the larger rank (i a non-proband)
+        if (v[u] > 0.f && !(mi.x & 1) && (mq[u].x & 1) && mq[u].x > mi.x) stale_append(so, mq[u].x >> 1, mi.x >> 1, v[u]);
     }
 }
 
-// the next active matrix: rows / columns = [survivors (old slots keep[s])..., new individuals...];
-// row and column n_next and the pitch padding are zero
+// survivors x survivors: next[r][c] = M[keep[r]][keep[c]] (keep ascending: a stream compaction)
 __global__ void __launch_bounds__(256)
-sparse_assemble_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old,
-                       const int2 *__restrict__ par, const float *__restrict__ T, long long ldT,
-                       const int *__restrict__ keep, int n_surv, int n_new, const int2 *__restrict__ meta_next,
-                       float *__restrict__ out, long long ld_out)
+sparse_compact_kernel(const float *__restrict__ M, long long ld, const int *__restrict__ keep, int n_surv, float *__restrict__ next,
+                      long long ld_next)
 {
-    const int r = blockIdx.x;                                    // 0 .. n_surv + n_new (the last one is the zero row)
-    const int n_next = n_surv + n_new;
-    for (int c = blockIdx.y * 256 + threadIdx.x; c < ld_out; c += gridDim.y * 256) {
-        float v = 0.f;
-        if (r < n_next && c < n_next) {
-            if (r < n_surv && c < n_surv) {
-                v = M[(long long)keep[r] * ld + keep[c]];
-            } else if (r >= n_surv && c < n_surv) {
-                v = T[(long long)(r - n_surv) * ldT + keep[c]];
-            } else if (r < n_surv) {
-                v = T[(long long)(c - n_surv) * ldT + keep[r]];
-            } else {
-                const int a = r - n_surv, b = c - n_surv;
-                if (a == b) {
-                    const int2 p = par[a];
-                    double cf = 0.5;
-                    if (p.x != n_old && p.y != n_old) cf += static_cast<double>(half32(lookup(M, ld, meta, p.x, p.y, n_old)));
-                    v = static_cast<float>(cf);
-                } else {
-                    const int i = max(a, b), j = min(a, b);      // j left the queue before i
-                    const int2 p = par[i];
-                    // the parents left the queue before j (an earlier wave): T[j][parent] sits under the key
-                    // (rank parent, rank j), which the lookup (smaller rank, larger rank) finds only when
-                    // rank parent < rank j -- always true for depth-sorted ranks, not with sort = false
-                    const int2 mj = meta_next[n_surv + j];
-                    const float tf = (p.x == n_old || !key_found(meta[p.x], mj)) ? 0.f : T[(long long)j * ldT + p.x];
-                    const float tm = (p.y == n_old || !key_found(meta[p.y], mj)) ? 0.f : T[(long long)j * ldT + p.y];
-                    v = static_cast<float>(0.0 + static_cast<double>(half32(tf)) + static_cast<double>(half32(tm)));
-                }
+    constexpr int U = 8;
+    const float *src = M + (long long)keep[blockIdx.x] * ld;
+    float *dst = next + (long long)blockIdx.x * ld_next;
+    const int c0 = blockIdx.y * (256 * U) + threadIdx.x;
+    int q[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = keep[min(c0 + u * 256, n_surv - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[q[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 256;
+        if (c < n_surv) dst[c] = v[u];
+    }
+}
+
+// new x new, in queue order (new index = position in the wave): row a holds the entries with the LATER ones
+// b > a and its own self kinship,
+//   next[n_surv + a][n_surv + b] = RN32(L'(a, f_b)/2 + L'(a, m_b)/2),  L'(a, p) = T[a][p] if rank(p) < rank(a) else 0
+//   next[n_surv + a][n_surv + a] = RN32(1/2 + L(f_a, m_a)/2)
+// Row a of T is staged in LDS when it fits (lds_floats >= n_old), else gathered from L2.
+__global__ void __launch_bounds__(256)
+sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                     const int2 *__restrict__ meta_new, const float *__restrict__ T, long long ldT, int n_new, int lds_floats,
+                     float *__restrict__ next, long long ld_next, int n_surv, StaleOut so)
+{
+    extern __shared__ float srow[];
+    const int a = blockIdx.x;
+    const float *trow = T + (long long)a * ldT;
+    const bool in_lds = lds_floats >= n_old;
+    if (in_lds && a + 1 < n_new) {                                // (uniform: a and n_new are)
+        const float4 *g4 = reinterpret_cast<const float4 *>(trow);
+        float4 *s4 = reinterpret_cast<float4 *>(srow);
+        for (int k = threadIdx.x; k < (n_old + 3) / 4; k += 256) s4[k] = g4[k];       // (T's pitch is a multiple of 64 floats)
+        __syncthreads();
+    }
+    const float *src = in_lds ? srow : trow;
+    const int2 ma = meta_new[a];
+    float *orow = next + (long long)(n_surv + a) * ld_next + n_surv;
+    if (threadIdx.x == 0) {
+        const int4 p = par[a];
+        double cf = 0.5;
+        if (p.x != n_old && p.y != n_old && (p.x == p.y || key_found(meta[p.x], meta[p.y])))
+            cf += static_cast<double>(half32(M[(long long)p.x * ld + p.y]));
+        orow[a] = static_cast<float>(cf);
+    }
+    for (int b0 = a + 1 + threadIdx.x; b0 < n_new; b0 += 4 * 256) {
+        int4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = par[min(b0 + u * 256, n_new - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * 256;
+            if (b >= n_new) break;
+            // the parents left the queue before a (an earlier wave): T[a][parent] sits under (rank parent, rank a),
+            // which the lookup (smaller rank, larger rank) finds only when rank parent < rank a
+            const float tf = (p[u].x != n_old && p[u].z < ma.x) ? src[p[u].x] : 0.f;
+            const float tm = (p[u].y != n_old && p[u].w < ma.x) ? src[p[u].y] : 0.f;
+            const float v = static_cast<float>(0.0 + static_cast<double>(half32(tf)) + static_cast<double>(half32(tm)));
+            orow[b] = v;
+            if (v > 0.f && (ma.x & 1)) {
+                const int2 mb = meta_new[b];                      // b is the later one: phi[rank_a][rank_b] outlives b's retirement
+                if (!(mb.x & 1) && ma.x > mb.x) stale_append(so, ma.x >> 1, mb.x >> 1, v);      // if a is a proband with the larger rank
             }
         }
-        out[(long long)r * ld_out + c] = v;
     }
 }
 
-__global__ void sparse_gather_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ rc, int n, float *__restrict__ out)
+// next[c][r] = next[r][c] for the new rows r >= n_surv and the columns c < n_surv (survivors x new) or c > r
+// (lower triangle of new x new); 64 x 64 tiles through LDS, both sides coalesced
+__global__ void __launch_bounds__(256)
+sparse_mirror_kernel(float *__restrict__ next, long long ld, int n_surv, int n_next)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = M[(long long)rc[k].x * ld + rc[k].y];
+    __shared__ float tile[64][65];
+    const int r0 = n_surv + blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if (c0 >= n_surv && c0 + 63 <= r0) return;                    // a tile on or below the diagonal of new x new with nothing to mirror
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < n_next && c < n_next && (c < n_surv || c > r)) ? next[(long long)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < n_next && c < n_next && (c < n_surv || c > r)) next[(long long)c * ld + r] = tile[tx][k];
+    }
 }
 
 long long pitch_of(long long n) { return ((n + 1) + 63) / 64 * 64; }
 
 struct Wave {
     int n_old = 0, n_new = 0, n_surv = 0;
-    std::vector<int2> par;        // per new individual: (father slot, mother slot) in the old active list
+    std::vector<int4> par;        // per new individual: (father slot, mother slot, 2 rank + pro of the father, of the mother); slots in the old active list
     std::vector<int> keep;        // old slots that survive the wave, ascending
-    std::vector<int2> meta_next;  // (rank, processing index) of the next active list
-    std::vector<int2> stale;      // (row slot, column slot) in the NEXT active matrix of entries to remember
+    std::vector<int> newpos;      // per old slot: its slot in the next list, or -1
+    std::vector<int2> meta_new;   // (2 rank + pro, processing index) of the new individuals, queue order
+    std::vector<int2> meta_old;   // ... of the old active list, slot order
+    size_t o_par = 0, o_keep = 0, o_newpos = 0, o_meta_new = 0, o_meta_old = 0;     // byte offsets in the device blob
 };
 
 }  // namespace
@@ -147,6 +243,11 @@ struct genphi_sparse {
     std::vector<int> stale_row_rank, stale_col_rank;   // entries that survive in a proband's dictionary
     std::vector<float> stale_val;
     std::unordered_map<int64_t, int> pos;     // ID -> index into ids
+    // measurement (genphi_sparse_stats)
+    double sweep_ms = 0.0, algorithmic_bytes = 0.0;
+    std::vector<float> wave_ms;
+    std::vector<double> wave_bytes;
+    int64_t max_active = 0;
 };
 
 extern "C" {
@@ -185,6 +286,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     const int m = static_cast<int>(orig.size());                 // rank of pruned index u is u + 1
     R->n_pro = static_cast<int64_t>(R->ids.size());
     if (m == 0) { *out = R; return GENPHI_OK; }
+    if (m >= (1 << 30)) return bail(GENPHI_ERR_ARG, "genphi_sparse_phi: more than 2^30 individuals");
     std::vector<int> pf(m), pm(m), depth(m), nchild(m, 0);
     std::vector<char> pro_flag(m);
     for (int u = 0; u < m; ++u) {
@@ -233,12 +335,13 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     for (int k = 1; k < m; ++k)
         if (depth[order[k]] < depth[order[k - 1]]) return bail(GENPHI_ERR_ARG, "internal: processing order is not depth-sorted");
 
-    // ---- waves: active lists, parents' slots, survivors, entries to remember ------------------------
+    // ---- waves: active lists, parents' slots, survivors; the layout of ONE device blob of every index array ----
+    auto meta_of = [&](int u) { return make_int2(2 * (u + 1) + (pro_flag[u] ? 1 : 0), proc[u]); };
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     std::vector<Wave> waves;
     std::vector<int> active;                                     // pruned indices, slot order
     std::vector<int> slot_of(m, -1);
-    std::vector<int> live_pro_ranks;                             // pruned indices (= rank - 1) of the probands processed so far, ascending
-    size_t max_mat = 64, max_T = 64, max_meta = 1, max_par = 1, n_stale = 0;
+    size_t max_mat = 64, max_T = 64, blob_bytes = 256;
     for (int b = 0; b < m;) {
         int e = b;
         while (e < m && depth[order[e]] == depth[order[b]]) ++e;
@@ -248,126 +351,181 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         const int last_proc = e - 1;
         for (int k = b; k < e; ++k) {
             const int u = order[k];
-            w.par.push_back(make_int2(pf[u] >= 0 ? slot_of[pf[u]] : w.n_old, pm[u] >= 0 ? slot_of[pm[u]] : w.n_old));
+            const int f = pf[u], mth = pm[u];
+            w.par.push_back(make_int4(f >= 0 ? slot_of[f] : w.n_old, mth >= 0 ? slot_of[mth] : w.n_old,
+                                      f >= 0 ? meta_of(f).x : 0, mth >= 0 ? meta_of(mth).x : 0));
+            w.meta_new.push_back(meta_of(u));
         }
         std::vector<int> next;
-        for (int s = 0; s < w.n_old; ++s)
-            if (retire[active[s]] > last_proc) { w.keep.push_back(s); next.push_back(active[s]); }
+        w.newpos.assign(w.n_old, -1);
+        w.meta_old.resize(w.n_old);
+        for (int s = 0; s < w.n_old; ++s) {
+            w.meta_old[s] = meta_of(active[s]);
+            if (retire[active[s]] > last_proc) { w.newpos[s] = static_cast<int>(next.size()); w.keep.push_back(s); next.push_back(active[s]); }
+        }
         w.n_surv = static_cast<int>(next.size());
         for (int k = b; k < e; ++k) next.push_back(order[k]);
-        for (size_t s = 0; s < next.size(); ++s) { slot_of[next[s]] = static_cast<int>(s); w.meta_next.push_back(make_int2(next[s] + 1, proc[next[s]])); }
-        // Entries that outlive their column (src/compute.jl:401-430): when a non-proband x retires, phi[rank j][rank x]
-        // is deleted only for live j with rank j < rank x.  The entry exists when j left the queue before x, so every
-        // proband j with proc(j) < proc(x) and rank(j) > rank(x) keeps it for good (`show` counts it, phiMean sums it) --
-        // j of an earlier wave included (only possible when ranks are not depth-sorted: sort = false).  Gathered right
-        // after the wave that processes x, while x's row is in the active matrix.  live_pro_ranks: ranks of the probands
-        // processed so far, ascending.
-        for (int kx = b; kx < e; ++kx) {
-            const int x = order[kx];
-            if (pro_flag[x]) { live_pro_ranks.insert(std::upper_bound(live_pro_ranks.begin(), live_pro_ranks.end(), x), x); continue; }
-            for (auto it = std::upper_bound(live_pro_ranks.begin(), live_pro_ranks.end(), x); it != live_pro_ranks.end(); ++it)
-                w.stale.push_back(make_int2(slot_of[*it], slot_of[x]));
-            if (n_stale + w.stale.size() > (size_t(1) << 28))
-                return bail(GENPHI_ERR_ALLOC, "genphi_sparse_phi: more than 2^28 entries outlive their column (ranks far from depth order)");
-        }
-        n_stale += w.stale.size();
+        for (size_t s = 0; s < next.size(); ++s) slot_of[next[s]] = static_cast<int>(s);
         max_mat = std::max(max_mat, static_cast<size_t>((next.size() + 1) * pitch_of(static_cast<long long>(next.size()))));
         max_T = std::max(max_T, static_cast<size_t>(w.n_new) * static_cast<size_t>(pitch_of(w.n_old)));
-        max_meta = std::max(max_meta, next.size() + 1);
-        max_par = std::max(max_par, w.par.size());
+        R->max_active = std::max<int64_t>(R->max_active, static_cast<int64_t>(next.size()));
+        R->wave_bytes.push_back(4.0 * (static_cast<double>(w.n_old) * w.n_old + static_cast<double>(next.size()) * next.size()));
+        w.o_par = blob_bytes; blob_bytes += al(w.par.size() * sizeof(int4));
+        w.o_keep = blob_bytes; blob_bytes += al(w.keep.size() * sizeof(int));
+        w.o_newpos = blob_bytes; blob_bytes += al(w.newpos.size() * sizeof(int));
+        w.o_meta_new = blob_bytes; blob_bytes += al(w.meta_new.size() * sizeof(int2));
+        w.o_meta_old = blob_bytes; blob_bytes += al(w.meta_old.size() * sizeof(int2));
         active.swap(next);
         waves.push_back(std::move(w));
         b = e;
     }
     // the final active list is exactly the probands
     if (static_cast<int64_t>(active.size()) != R->n_pro) return bail(GENPHI_ERR_ARG, "internal: final active set is not the proband set");
+    std::vector<char> blob(blob_bytes, 0);
+    for (Wave &w : waves) {
+        std::memcpy(blob.data() + w.o_par, w.par.data(), w.par.size() * sizeof(int4));
+        std::memcpy(blob.data() + w.o_keep, w.keep.data(), w.keep.size() * sizeof(int));
+        std::memcpy(blob.data() + w.o_newpos, w.newpos.data(), w.newpos.size() * sizeof(int));
+        std::memcpy(blob.data() + w.o_meta_new, w.meta_new.data(), w.meta_new.size() * sizeof(int2));
+        std::memcpy(blob.data() + w.o_meta_old, w.meta_old.data(), w.meta_old.size() * sizeof(int2));
+        std::vector<int4>().swap(w.par); std::vector<int>().swap(w.keep); std::vector<int>().swap(w.newpos);
+        std::vector<int2>().swap(w.meta_new); std::vector<int2>().swap(w.meta_old);
+    }
+    for (double x : R->wave_bytes) R->algorithmic_bytes += x;
 
-    // ---- the device sweep ------------------------------------------------------------------------------
+    // ---- the device sweep: every launch of every wave in stream order, one synchronisation at the end ------
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return bail(GENPHI_ERR_DEVICE, "no HIP device available: gen.sparse_phi has no CPU fallback");
     if (device >= 0) { if (device >= ndev) return bail(GENPHI_ERR_DEVICE, "device ordinal out of range"); (void)hipSetDevice(device); }
-    float *dM[2] = {nullptr, nullptr}, *dT = nullptr, *d_stale = nullptr;
-    int2 *d_meta[2] = {nullptr, nullptr}, *d_par = nullptr, *d_rc = nullptr;
-    int *d_keep = nullptr;
+    float *dM[2] = {nullptr, nullptr}, *dT = nullptr, *d_sval = nullptr;
+    char *d_blob = nullptr;
+    int2 *d_src = nullptr;
+    int *d_cnt = nullptr;
     hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
     auto cleanup = [&]() {
-        (void)hipFree(dM[0]); (void)hipFree(dM[1]); (void)hipFree(dT); (void)hipFree(d_stale); (void)hipFree(d_meta[0]); (void)hipFree(d_meta[1]);
-        (void)hipFree(d_par); (void)hipFree(d_rc); (void)hipFree(d_keep);
+        (void)hipFree(dM[0]); (void)hipFree(dM[1]); (void)hipFree(dT); (void)hipFree(d_sval); (void)hipFree(d_blob); (void)hipFree(d_src); (void)hipFree(d_cnt);
+        dM[0] = dM[1] = dT = d_sval = nullptr; d_blob = nullptr; d_src = nullptr; d_cnt = nullptr;
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
         if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
     };
 #define SP_GO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return bail(GENPHI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
-        SP_GO(hipMalloc(reinterpret_cast<void **>(&dM[k]), max_mat * sizeof(float)));
-        SP_GO(hipMalloc(reinterpret_cast<void **>(&d_meta[k]), max_meta * sizeof(int2)));
+    int stale_cap = 1 << 16, n_stale = 0;
+    const bool timed = waves.size() <= 4096;
+    size_t max_lds = 0;
+    for (const Wave &w : waves) if (w.n_new > 1 && w.n_old <= 36864) max_lds = std::max(max_lds, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
+    for (int attempt = 0; attempt < 2; ++attempt) {               // (a second sweep only if the list of outliving entries overflowed)
+        SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) SP_GO(hipMalloc(reinterpret_cast<void **>(&dM[k]), max_mat * sizeof(float)));
+        SP_GO(hipMalloc(reinterpret_cast<void **>(&dT), max_T * sizeof(float)));
+        SP_GO(hipMalloc(reinterpret_cast<void **>(&d_blob), blob_bytes));
+        SP_GO(hipMalloc(reinterpret_cast<void **>(&d_sval), static_cast<size_t>(stale_cap) * sizeof(float)));
+        SP_GO(hipMalloc(reinterpret_cast<void **>(&d_src), static_cast<size_t>(stale_cap) * sizeof(int2)));
+        SP_GO(hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(int)));
+        SP_GO(hipMemcpyAsync(d_blob, blob.data(), blob_bytes, hipMemcpyHostToDevice, st));
+        SP_GO(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+        if (max_lds > 48 * 1024)
+            SP_GO(hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_newnew_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)));
+        if (timed) { ev.resize(waves.size() + 1); for (hipEvent_t &e : ev) SP_GO(hipEventCreate(&e)); SP_GO(hipEventRecord(ev[0], st)); }
+        StaleOut so; so.cnt = d_cnt; so.cap = stale_cap; so.rc = d_src; so.val = d_sval;
+        long long ld_cur = pitch_of(0);
+        int cur = 0;
+        for (size_t wi = 0; wi < waves.size(); ++wi) {
+            const Wave &w = waves[wi];
+            const int n_next = w.n_surv + w.n_new;
+            const long long ldT = pitch_of(w.n_old), ld_next = pitch_of(n_next);
+            const int4 *d_par = reinterpret_cast<const int4 *>(d_blob + w.o_par);
+            const int *d_keep = reinterpret_cast<const int *>(d_blob + w.o_keep), *d_newpos = reinterpret_cast<const int *>(d_blob + w.o_newpos);
+            const int2 *d_meta_new = reinterpret_cast<const int2 *>(d_blob + w.o_meta_new), *d_meta_old = reinterpret_cast<const int2 *>(d_blob + w.o_meta_old);
+            if (w.n_new > 0 && w.n_old > 0) {
+                dim3 grid(static_cast<unsigned>(w.n_new), static_cast<unsigned>((w.n_old + 1023) / 1024));
+                hipLaunchKernelGGL(sparse_rows_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new,
+                                   d_newpos, dT, ldT, dM[cur ^ 1], ld_next, w.n_surv, so);
+                SP_GO(hipGetLastError());
+            }
+            if (w.n_surv > 0) {
+                dim3 grid(static_cast<unsigned>(w.n_surv), static_cast<unsigned>((w.n_surv + 2047) / 2048));
+                hipLaunchKernelGGL(sparse_compact_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_keep, w.n_surv, dM[cur ^ 1], ld_next);
+                SP_GO(hipGetLastError());
+            }
+            if (w.n_new > 0) {
+                const int lds_floats = w.n_old <= 36864 ? (w.n_old + 3) / 4 * 4 : 0;
+                hipLaunchKernelGGL(sparse_newnew_kernel, dim3(static_cast<unsigned>(w.n_new)), dim3(256), static_cast<size_t>(lds_floats) * sizeof(float), st,
+                                   dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new, dT, ldT, w.n_new, w.n_old > 0 ? lds_floats : 0,
+                                   dM[cur ^ 1], ld_next, w.n_surv, so);
+                SP_GO(hipGetLastError());
+                dim3 grid(static_cast<unsigned>((n_next + 63) / 64), static_cast<unsigned>((w.n_new + 63) / 64));
+                hipLaunchKernelGGL(sparse_mirror_kernel, grid, dim3(256), 0, st, dM[cur ^ 1], ld_next, w.n_surv, n_next);
+                SP_GO(hipGetLastError());
+            }
+            if (timed) SP_GO(hipEventRecord(ev[wi + 1], st));
+            cur ^= 1;
+            ld_cur = ld_next;
+        }
+        SP_GO(hipMemcpyAsync(&n_stale, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+        SP_GO(hipStreamSynchronize(st));
+        if (n_stale > stale_cap) {                                // more entries outlive their columns than the list holds: once more, sized exactly
+            if (attempt == 1 || n_stale > (1 << 28)) { cleanup(); return bail(GENPHI_ERR_ALLOC, "genphi_sparse_phi: too many entries outlive their columns"); }
+            stale_cap = n_stale;
+            cleanup();
+            continue;
+        }
+        // ---- results: the proband x proband block, the remembered entries, the timings ------------------------
+        const int64_t N = R->n_pro;
+        R->S.resize(static_cast<size_t>(N * N));
+        if (N > 0)
+            SP_GO(hipMemcpy2D(R->S.data(), N * sizeof(float), dM[cur], ld_cur * sizeof(float), N * sizeof(float), N, hipMemcpyDeviceToHost));
+        if (n_stale) {
+            std::vector<int2> rc(n_stale);
+            std::vector<float> sv(n_stale);
+            SP_GO(hipMemcpy(rc.data(), d_src, static_cast<size_t>(n_stale) * sizeof(int2), hipMemcpyDeviceToHost));
+            SP_GO(hipMemcpy(sv.data(), d_sval, static_cast<size_t>(n_stale) * sizeof(float), hipMemcpyDeviceToHost));
+            // the append order depends on the scheduling of the workgroups: sort for a reproducible list
+            std::vector<int> o(n_stale);
+            for (int k = 0; k < n_stale; ++k) o[k] = k;
+            std::sort(o.begin(), o.end(), [&](int x, int y) { return rc[x].x != rc[y].x ? rc[x].x < rc[y].x : rc[x].y < rc[y].y; });
+            for (int k = 0; k < n_stale; ++k) { R->stale_row_rank.push_back(rc[o[k]].x); R->stale_col_rank.push_back(rc[o[k]].y); R->stale_val.push_back(sv[o[k]]); }
+        }
+        if (timed) {
+            float ms = 0.f;
+            SP_GO(hipEventElapsedTime(&ms, ev[0], ev[waves.size()]));
+            R->sweep_ms = ms;
+            R->wave_ms.resize(waves.size());
+            for (size_t wi = 0; wi < waves.size(); ++wi) SP_GO(hipEventElapsedTime(&R->wave_ms[wi], ev[wi], ev[wi + 1]));
+        }
+        cleanup();
+        break;
     }
-    SP_GO(hipMalloc(reinterpret_cast<void **>(&dT), max_T * sizeof(float)));
-    SP_GO(hipMalloc(reinterpret_cast<void **>(&d_par), max_par * sizeof(int2)));
-    SP_GO(hipMalloc(reinterpret_cast<void **>(&d_keep), max_meta * sizeof(int)));
-    SP_GO(hipMalloc(reinterpret_cast<void **>(&d_stale), std::max<size_t>(n_stale, 1) * sizeof(float)));
-    SP_GO(hipMalloc(reinterpret_cast<void **>(&d_rc), std::max<size_t>(n_stale, 1) * sizeof(int2)));
-    SP_GO(hipMemsetAsync(dM[0], 0, max_mat * sizeof(float), st));           // the empty active set: a zero "none" row
-    size_t stale_done = 0;
-    long long ld_cur = pitch_of(0);
-    int cur = 0;
-    for (const Wave &w : waves) {
-        const int n_next = w.n_surv + w.n_new;
-        const long long ldT = pitch_of(w.n_old), ld_next = pitch_of(n_next);
-        SP_GO(hipMemcpyAsync(d_par, w.par.data(), w.par.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        if (!w.keep.empty()) SP_GO(hipMemcpyAsync(d_keep, w.keep.data(), w.keep.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        SP_GO(hipMemcpyAsync(d_meta[cur ^ 1], w.meta_next.data(), w.meta_next.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        {
-            dim3 grid(static_cast<unsigned>(w.n_new), static_cast<unsigned>(std::min<long long>((ldT + 255) / 256, 64)));
-            hipLaunchKernelGGL(sparse_new_old_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta[cur], w.n_old, d_par, dT, ldT);
-            SP_GO(hipGetLastError());
-        }
-        {
-            dim3 grid(static_cast<unsigned>(n_next + 1), static_cast<unsigned>(std::min<long long>((ld_next + 255) / 256, 64)));
-            hipLaunchKernelGGL(sparse_assemble_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta[cur], w.n_old, d_par, dT, ldT,
-                               d_keep, w.n_surv, w.n_new, d_meta[cur ^ 1], dM[cur ^ 1], ld_next);
-            SP_GO(hipGetLastError());
-        }
-        if (!w.stale.empty()) {
-            SP_GO(hipMemcpyAsync(d_rc + stale_done, w.stale.data(), w.stale.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-            const int n = static_cast<int>(w.stale.size());
-            hipLaunchKernelGGL(sparse_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dM[cur ^ 1], ld_next, d_rc + stale_done, n,
-                               d_stale + stale_done);
-            SP_GO(hipGetLastError());
-            stale_done += w.stale.size();
-        }
-        SP_GO(hipStreamSynchronize(st));                         // the wave's host arrays are reused by the next one
-        cur ^= 1;
-        ld_cur = ld_next;
-    }
-    // ---- results: the proband x proband block and the remembered entries ---------------------------------
-    const int64_t N = R->n_pro;
-    R->S.resize(static_cast<size_t>(N * N));
-    if (N > 0)
-        SP_GO(hipMemcpy2D(R->S.data(), N * sizeof(float), dM[cur], ld_cur * sizeof(float), N * sizeof(float), N, hipMemcpyDeviceToHost));
-    R->stale_val.resize(n_stale);
-    if (n_stale) SP_GO(hipMemcpy(R->stale_val.data(), d_stale, n_stale * sizeof(float), hipMemcpyDeviceToHost));
-    cleanup();
 #undef SP_GO
+    const int64_t N = R->n_pro;
     R->rank.resize(N); R->proc.resize(N); R->slot.resize(N);
     for (int64_t k = 0; k < N; ++k) {
         const int u = iso_of[at[R->ids[k]]];
         R->rank[k] = u + 1; R->proc[k] = proc[u]; R->slot[k] = slot_of[u];
     }
-    {   // ranks of the remembered entries, in the order they were gathered: replay the active lists
-        std::vector<int> active2;
-        for (int b = 0, wi = 0; b < m; ++wi) {
-            int e = b;
-            while (e < m && depth[order[e]] == depth[order[b]]) ++e;
-            std::vector<int> next;
-            for (int s : waves[wi].keep) next.push_back(active2[s]);
-            for (int q = b; q < e; ++q) next.push_back(order[q]);
-            for (const int2 &rc : waves[wi].stale) { R->stale_row_rank.push_back(next[rc.x] + 1); R->stale_col_rank.push_back(next[rc.y] + 1); }
-            active2.swap(next);
-            b = e;
-        }
-    }
     *out = R;
+    return GENPHI_OK;
+}
+
+/* Measurement of the sweep that built the handle: waves (depths), device time of the whole sweep and of every
+ * wave (HIP events on the sweep's stream), algorithmic bytes 4 (n_old^2 + n_next^2) per wave (the old active
+ * matrix read once, the next one written once), the largest active set. */
+int genphi_sparse_stats(const genphi_sparse *h, int32_t *n_waves, double *sweep_ms, double *algorithmic_bytes, int64_t *max_active,
+                        float *wave_ms, double *wave_bytes, int32_t cap)
+{
+    if (!h) return genphi_set_error(GENPHI_ERR_ARG, "sparse handle is NULL");
+    const int32_t nw = static_cast<int32_t>(h->wave_bytes.size());
+    if (n_waves) *n_waves = nw;
+    if (sweep_ms) *sweep_ms = h->sweep_ms;
+    if (algorithmic_bytes) *algorithmic_bytes = h->algorithmic_bytes;
+    if (max_active) *max_active = h->max_active;
+    for (int32_t k = 0; k < nw && k < cap; ++k) {
+        if (wave_ms) wave_ms[k] = k < static_cast<int32_t>(h->wave_ms.size()) ? h->wave_ms[k] : 0.f;
+        if (wave_bytes) wave_bytes[k] = h->wave_bytes[k];
+    }
     return GENPHI_OK;
 }
 

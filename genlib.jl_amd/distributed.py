@@ -64,14 +64,23 @@ def panel_sweep(pl, dist, dev):
         n_s = max([int(s.sum()) * cf for s, _, cf in counts] + [1])
         n_r = max([int(r.sum()) * cf for _, r, cf in counts] + [1])
         bufs = pl._xbufs = (torch.empty(n_s, dtype=torch.float32, device=dev), torch.empty(n_r, dtype=torch.float32, device=dev))
+    import time
     send, recv = bufs
     sent = 0
+    t_pack = t_xchg = t_comp = 0.0
     for step, (s_cols, r_cols, cf) in enumerate(counts):
+        t0 = time.perf_counter()
         pl.pack(step, send.data_ptr())
+        t1 = time.perf_counter()
         _exchange(dist, send, recv, s_cols, r_cols, cf)
         torch.cuda.current_stream(dev).synchronize()
+        t2 = time.perf_counter()
         pl.compute(step, recv.data_ptr())
+        t3 = time.perf_counter()
+        t_pack += t1 - t0; t_xchg += t2 - t1; t_comp += t3 - t2
         sent += int(s_cols.sum()) * cf * 4
+    # host wall time of the three phases of the last sweep (each ends with a stream synchronisation)
+    pl.last_sweep = {"pack_ms": t_pack * 1e3, "exchange_ms": t_xchg * 1e3, "compute_ms": t_comp * 1e3}
     return sent
 
 

@@ -192,7 +192,7 @@ int genphi_plan_release_device(genphi_plan *plan);
  * each kinship is RN32(phi[father, j]/2 + phi[mother, j]/2), parents are dropped when their children
  * are done, and the result is a dictionary of the probands' non-zero kinships keyed by rank.  Here the
  * queue is simulated on the host (integers only) and all individuals of one depth are computed by two
- * kernel launches on a dense "active" matrix in HBM (csrc/sparse_phi.hip).  Values, getindex
+ * streaming kernels on a dense "active" matrix in HBM (csrc/sparse_phi.hip).  Values, getindex
  * semantics (incl. the reference's (earlier, later) vs (smaller, larger rank) key behaviour), the
  * number of stored entries `show` prints and phiMean's sums are those of the reference.
  *   genphi_sparse_phi      sparse_phi(pedigree, probandIDs); pedigree in rank order as for
@@ -207,6 +207,11 @@ typedef struct genphi_sparse genphi_sparse;
 int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
                       int64_t n_pro, const int64_t *pro_ids, int32_t device, genphi_sparse **out);
 int genphi_sparse_info(const genphi_sparse *h, int64_t *n_rows, int64_t *n_stored, double *sum_all, double *sum_diag);
+/* Measurement of the sweep that built the handle: number of waves (depths), device time of the sweep and of each
+ * wave (HIP events on its stream; the first `cap` waves), algorithmic bytes 4 (n_old^2 + n_next^2) per wave (the
+ * active matrix read once, the next one written once) and in total, the largest active set.  Any pointer may be NULL. */
+int genphi_sparse_stats(const genphi_sparse *h, int32_t *n_waves, double *sweep_ms, double *algorithmic_bytes,
+                        int64_t *max_active, float *wave_ms, double *wave_bytes, int32_t cap);
 int genphi_sparse_get(const genphi_sparse *h, int64_t n, const int64_t *id1, const int64_t *id2, double *out);
 int64_t genphi_sparse_entries(const genphi_sparse *h, int64_t cap, int64_t *row_rank, int64_t *col_rank, float *val);
 void genphi_sparse_destroy(genphi_sparse *h);
@@ -228,6 +233,7 @@ typedef struct genphi_panel genphi_panel;
 int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
                         int64_t n_pro, const int64_t *pro_ids, int32_t rank, int32_t world, genphi_panel **out);
 int64_t genphi_panel_n_steps(const genphi_panel *p);
+double genphi_panel_step_ms(const genphi_panel *p, int32_t step);  /* device time of the step's kernels (unpack + level) in the last sweep, HIP events; -1 bad argument */
 int genphi_panel_step_mode(const genphi_panel *p, int32_t step);   /* 0 FULL / 1 SPLIT row kernels on the local columns, 2 per-entry kernel; -1 bad argument */
 int64_t genphi_panel_n_probands(const genphi_panel *p);
 int genphi_panel_result_rows(const genphi_panel *p, int64_t *row_begin, int64_t *n_rows);

@@ -901,10 +901,12 @@ def test_sparse_phi_unsorted_ranks(gen, oracle):
             a, b = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=True)
             n_cross += K.info()[1] != a.info()[1]
     assert n_cross >= 3                                                     # the file order really changes what is stored
-    g = oracle.read_tsv(gen.genea140)                                       # genea140 in its own file order (not depth-sorted)
+    g = oracle.read_tsv(gen.genea140)                                       # genea140 in its own file order, and shuffled parents-first
     ped = gen.genealogy(gen.genea140, sort=False)
-    assert not np.array_equal(ped.ind, gen.genealogy(gen.genea140).ind)
+    assert np.array_equal(ped.ind, g[0])
     _sparse_check(gen, oracle, *g, pro=gen.pro(ped)[:25], sort=False)
+    g2 = synth.parents_first_shuffle(*g, seed=11)
+    _sparse_check(gen, oracle, *g2, pro=gen.pro(ped)[5:30], sort=False)
 
 
 def test_dense_phi_f_and_pairs_with_unsorted_ranks(gen, oracle, monkeypatch):
@@ -953,9 +955,9 @@ def test_dense_phi_f_and_pairs_with_unsorted_ranks(gen, oracle, monkeypatch):
             a = np.random.default_rng(seed + 7).choice(i2, 16); b = np.random.default_rng(seed + 8).choice(i2, 16)
             got = _capi.phi_pairs(ped.ind, ped.father, ped.mother, a, b)
             assert np.array_equal(got, np.array([oped.phi_pair(int(x), int(y)) for x, y in zip(a, b)]))
-    # genea140 in file order
-    ped = gen.genealogy(gen.genea140, sort=False)
-    g = oracle.read_tsv(gen.genea140)
+    # genea140 in a shuffled parents-first file order (its own file happens to be depth-sorted already)
+    g = synth.parents_first_shuffle(*oracle.read_tsv(gen.genea140), seed=5)
+    ped = gen.genealogy({"ind": g[0], "father": g[1], "mother": g[2], "sex": g[3]}, sort=False)
     oped = oracle.Pedigree(g[0], g[1], g[2], sort=False)
     _assert_equal(gen.phi(ped), oped.phi())
 
