@@ -41,7 +41,7 @@ class GenphiStats(C.Structure):
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info",
-    "genphi_plan_algorithmic_bytes", "genphi_compute_device", "genphi_result_device",
+    "genphi_plan_algorithmic_bytes", "genphi_plan_step_walk", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
@@ -81,6 +81,10 @@ def lib():
         L.genphi_plan_step_mode.restype = C.c_int
         L.genphi_plan_step_info.argtypes = [C.c_void_p, C.c_int32, _I64P]
         L.genphi_plan_step_info.restype = C.c_int
+        _I32P = C.POINTER(C.c_int32)
+        if hasattr(L, "genphi_plan_step_walk"):            # (absent from older builds used in same-box A/B runs)
+            L.genphi_plan_step_walk.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P, _I32P, _I32P, _I32P]
+            L.genphi_plan_step_walk.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -274,6 +278,20 @@ class PhiPlan:
         if rc:
             _raise(rc)
         return tuple(int(x) for x in out)
+
+    def step_walk(self, step):
+        """Work lists of SPLIT level step `step` (the hub walk, csrc/planner.h): (desc, seg, run) as int32 arrays of
+        shape (rows, 4), (segments, 4), (runs, 2), terminators dropped."""
+        nr, ns, nu = C.c_int64(), C.c_int64(), C.c_int64()
+        rc = lib().genphi_plan_step_walk(self._h, int(step), C.byref(nr), C.byref(ns), C.byref(nu), None, None, None)
+        if rc:
+            _raise(rc)
+        desc = np.zeros((nr.value, 4), np.int32); seg = np.zeros((ns.value + 2, 4), np.int32); run = np.zeros((nu.value + 1, 2), np.int32)
+        i32 = C.POINTER(C.c_int32)
+        rc = lib().genphi_plan_step_walk(self._h, int(step), None, None, None, desc.ctypes.data_as(i32), seg.ctypes.data_as(i32), run.ctypes.data_as(i32))
+        if rc:
+            _raise(rc)
+        return desc, seg, run
 
     def step_modes(self):
         """Kernel family per level step: 0 FULL, 1 SPLIT, 2 WIDE."""

@@ -373,7 +373,7 @@ __device__ unsigned long long g_wg_phase[2][1024][16];   // [thread 0 | last thr
 
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int *__restrict__ glist, int *queue)
+level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int *__restrict__ glist, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -447,7 +447,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
     int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
     int chunk = it - gk * p.n_chunks;
     int g = glist ? glist[gk] : gk;                       // (a restrict kernel argument: scalar loads, see level_split_fast_kernel)
-    int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
+    // an item of this kernel is ONE segment (hub row, its rows without B source first, then <= 4 children with one)
+    int wb = seg[g].x, we = seg[g + 1].x, Ai = seg[g].y, n0 = seg[g].z;
     int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
     bool have_next = nxt_l < n_items;
@@ -482,7 +483,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         int4 dsc = make_int4(0, 0, 0, 0);
         int nextB;                                      // B source of the next child, or n_prev
         if (stage_is_a) {
-            nextB = desc[wb].z;
+            nextB = (wb + n0 < we) ? desc[wb + n0].z : p.n_prev;
         } else {
             dsc = desc[w];
             nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
@@ -501,7 +502,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         const int next_item = nxt_l;
         const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
         const int gn = glist ? glist[gkn] : gkn;
-        const int nextAi = grp[gn].y;
+        const int nextAi = seg[gn].y;
         // ---- part 1: index loads of this stage and the queue draw, BEFORE the prefetch (vmcnt retires in
         //      order, so the gathers below only wait for these) and before the first barrier: their
         //      registers are dead here, and the prefetch can then follow the LDS writes piece by piece ----
@@ -519,10 +520,11 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                     const i4_t v = ld_off<i4_t>(p.ord_col, (cb + q * 4 * NT + tl * 4) * 4u);
                     oj[4 * q] = v.x; oj[4 * q + 1] = v.y; oj[4 * q + 2] = v.z; oj[4 * q + 3] = v.w;
                 }
-                const int o0 = desc[wb].w & kOrdMask;
-                const int o1 = desc[min(wb + 1, we - 1)].w & kOrdMask;
-                const int o2 = desc[min(wb + 2, we - 1)].w & kOrdMask;
-                const int o3 = desc[min(wb + 3, we - 1)].w & kOrdMask;
+                const int wc = wb + n0;                 // the segment's children with a B source (<= 4)
+                const int o0 = desc[min(wc, we - 1)].w & kOrdMask;
+                const int o1 = desc[min(wc + 1, we - 1)].w & kOrdMask;
+                const int o2 = desc[min(wc + 2, we - 1)].w & kOrdMask;
+                const int o3 = desc[min(wc + 3, we - 1)].w & kOrdMask;
                 hb0 = hb1 = hb2 = hb3 = 0;
 #pragma unroll
                 for (int k = CPT - 1; k >= 0; --k) {    // shift-accumulate: bit k ends up at position k
@@ -564,8 +566,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         if (stage_is_a) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) { pa[k] = sR[pk[k] & 0xffff]; pb[k] = sR[pk[k] >> 16]; }
-            wfin_b = wb;                                // if the first child has no B, none has
-            wfin_e = (nextB == p.n_prev) ? we : wb;
+            wfin_b = wb;                                // the hub's rows without a B source lead the segment
+            wfin_e = wb + n0;
         } else {
             const int ri = dsc.x, orow = dsc.y, oi = dsc.w;
             const bool new_i = oi < 0;
@@ -574,7 +576,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
             // diagonal of a new member: 1/2 + Psi[A][B]/2 = 1/2 + Psi[B][A]/2 (bit-symmetric)
             const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
             const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[p.pdesc ? p.pdesc[w].y : Ai]));
-            const int qk = w - wb;                      // which child of the group (wave-uniform)
+            const int qk = w - (wb + n0);               // which child of the segment (wave-uniform)
             const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
             unsigned ck = 0xffffffffu;                   // smallest cert_key of the entries written
@@ -602,10 +604,10 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
                 if ((unsigned)dcol >= cb && (unsigned)dcol < ce && ((r >> 2) & (NT - 1)) == tl)
                     st_off<float>(orowp, (unsigned)dcol * 4u, diag);
             }
-            wfin_b = w + 1;
-            wfin_e = (nextB == p.n_prev) ? we : w + 1;
+            wfin_b = 0;
+            wfin_e = 0;
         }
-        // children without a B source (dragged or one-parent rows): finish from the A-row terms
+        // rows without a B source (dragged or one-parent rows of the hub): finish from the A-row terms
         for (int wf = wfin_b; wf < wfin_e; ++wf) {
             unsigned z1 = 0, tlf = tl;                  // opaque again: nothing per-column may be hoisted
             asm volatile("" : "+s"(z1));
@@ -638,14 +640,14 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
         GENPHI_PHASE(4);                                // gathers, combine, row stores
         // ---- advance the stage state ----
         if (nextB != p.n_prev) {                        // next stage: B row of the next child
-            w = stage_is_a ? wb : w + 1;
+            w = stage_is_a ? wb + n0 : w + 1;
             stage_is_a = false;
         } else {                                        // next stage: row A of the next item
             if (!have_next) break;
             it = next_item;
             g = gn; gk = gkn;
             chunk = it - gk * p.n_chunks;
-            wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
+            wb = seg[g].x; we = seg[g + 1].x; Ai = nextAi; n0 = seg[g].z;
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
@@ -671,16 +673,16 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 
 // Bit-identical to the grouping-exact kernel on certified rows (tests force both on the same input).
 template <int NTHREADS, int CPT, int STG, bool CERT>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int *__restrict__ glist,
-                        int *queue)
+level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int2 *__restrict__ run,
+                        const int *__restrict__ glist, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
     float *sR = lds;
-    const int n_items = p.gcnt[0] * p.n_chunks;           // certified groups of this launch (group_split_kernel)
+    const int n_items = p.gcnt[0] * p.n_chunks;           // certified runs of this launch (group_split_kernel) x column chunks
     const int xcd = blockIdx.x & 7;
     const int q = n_items >> 3, rem = n_items & 7;
-    auto draw = [&]() -> int {                            // next item of a certified group, or n_items
+    auto draw = [&]() -> int {                            // next item of a certified run, or n_items
 #pragma unroll 1
         for (int t = 0; t < 8; ++t) {
             const int x = (xcd + t) & 7;
@@ -693,7 +695,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         float *zr = p.out + (long long)p.zrow * p.ld;
         for (long long j = threadIdx.x; j < p.ld; j += NT) zr[j] = 0.f;
     }
-    if (n_items == 0) return;                             // no certified group in this launch
+    if (n_items == 0) return;                             // no certified run in this launch
     int *slot = reinterpret_cast<int *>(lds + p.slot_off);   // queue hand-over slots (thread 0 draws one item ahead)
     if (threadIdx.x == 0) {
         slot[0] = draw();
@@ -709,22 +711,31 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
 
     f4_t pre[STG];
     unsigned pk[CPT];                                     // A_j | B_j << 16 of this thread's columns
-    double pab[CPT];                                      // (a + b) / 4 of this thread's columns
+    double pab[CPT];                                      // (a + b) / 4 of this thread's columns: the expansion of the current hub row
     static_assert(CPT % 4 == 0, "columns are handled in quads");
     constexpr int NQ = CPT / 4;
 
-    int it = cur_l;
-    int gk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(it), p.chunk_magic)) : it);   // position in this launch's group list
-    int chunk = it - gk * p.n_chunks;
-    // (glist is a kernel argument of its own, const and restrict: its loads are scalar.  Read through the
-    // argument struct they were vector loads, and waiting for one drains vmcnt -- row stores included)
-    int g = glist[gk];
-    int wb = grp[g].x, we = grp[g + 1].x, Ai = grp[g].y;
-    int w = wb;
+    // ---- stage state (all wave-uniform).  An item is (run, column chunk); a run is a list of segments (see
+    //      GroupLists): the first one stages its hub row (stage A), every child with a B source is a stage B, and
+    //      the expansion of a segment's last B row becomes the hub of a following type-1 segment for free. ----
+    // (few scalars are kept across stages -- the kernel is at the SGPR limit, and a scalar spilled to a VGPR lane costs
+    // a vector register of the column state; what a stage needs beyond them is re-read from the scalar cache)
+    int g, g_end, wb, we, n0, Ai;                         // current segment, end of the run, the segment's rows, its hub row
+    unsigned cb, ce;                                      // column chunk [cb, ce)
+    {
+        const int rk = (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(cur_l), p.chunk_magic)) : cur_l);   // position in this launch's run list
+        const int chunk = cur_l - rk * p.n_chunks;
+        // (glist is a kernel argument of its own, const and restrict: its loads are scalar.  Read through the
+        // argument struct they were vector loads, and waiting for one drains vmcnt -- row stores included)
+        const int r = glist[rk];
+        g = run[r].x; g_end = run[r + 1].x;
+        wb = seg[g].x; we = seg[g + 1].x; n0 = seg[g].z; Ai = seg[g].y;
+        cb = (unsigned)chunk * (unsigned)p.chunk_cols;
+        ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
+    }
+    int w = wb;                                           // child whose B row is the current stage (B stages)
     bool stage_is_a = true;
     bool have_next = nxt_l < n_items;
-    unsigned cb = (unsigned)chunk * (unsigned)p.chunk_cols;
-    unsigned ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
 
 #pragma unroll
     for (int k_ = 0; k_ < STG; ++k_) pre[k_] = ld_off<f4_t>(p.psi + (long long)Ai * p.ld_prev, (tl + k_ * NT) * 16u);
@@ -734,23 +745,39 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         __builtin_assume(tl < NT);
 
         // ---- part 0: scalar descriptors of the stage, ahead of the barriers ----
-        int4 dsc = make_int4(0, 0, 0, 0);
-        int nextB;
+        // (everything the NEXT stage needs is loaded here, one stage ahead and in front of the barriers: a scalar load
+        // that misses the scalar cache takes ~1 us, and a chain of dependent ones at the start of a stage is exposed)
+        int4 dsc = make_int4(0, 0, 0, 0);                 // (stage B) storage row, output row, staged row of child w
+        int nextB;                                        // B row of the next stage, or n_prev when the next stage is another item's stage A
+        bool seg_step = false, chain = false;             // this stage is the last child of its segment and the run goes on; ... with the staged row as the hub
+        int4 nsg = make_int4(0, 0, 0, 0);                 // the segment the run goes on with
+        int n_we = 0;
         if (stage_is_a) {
-            nextB = desc[wb].z;
+            nextB = (wb + n0 < we) ? desc[wb + n0].z : p.n_prev;
         } else {
             dsc = desc[w];
-            nextB = (w + 1 < we) ? desc[w + 1].z : p.n_prev;
+            if (w + 1 < we) {
+                nextB = desc[w + 1].z;
+            } else if (g + 1 < g_end) {
+                seg_step = true;
+                nsg = seg[g + 1];
+                n_we = seg[g + 2].x;
+                chain = nsg.w == 1;
+                nextB = (nsg.x + nsg.z < n_we) ? desc[nsg.x + nsg.z].z : p.n_prev;
+            } else {
+                nextB = p.n_prev;
+            }
         }
+        const int ri = dsc.x, orow = dsc.y, Bi = dsc.z;
         // (the hand-over slot read below was written at least one barrier ago: stage A of the previous item)
         if (stage_is_a && kc > 0) {
             nxt_l = __builtin_amdgcn_readfirstlane(slot[(kc - 1) & 1]);
             have_next = nxt_l < n_items;
         }
-        const int next_item = nxt_l;
-        const int gkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(next_item), p.chunk_magic)) : next_item) : gk;
-        const int gn = glist[gkn];
-        const int nextAi = grp[gn].y;
+        // the next item's run (a dummy one when nothing is left: an unconditional prefetch keeps `pre` in one set)
+        const int rkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(nxt_l), p.chunk_magic)) : nxt_l) : 0;
+        const int rn = glist[rkn];
+        const int gn = run[rn].x, nextAi = run[rn].y;     // its first segment and that segment's hub row
         // index loads and the queue draw BEFORE the prefetch (vmcnt retires in order); the prefetch itself
         // is issued piece by piece as the LDS writes free the staging registers, so it leads by the LDS
         // writes and the second barrier
@@ -775,15 +802,8 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         __syncthreads();
 
         // ---- part 2: gathers from the staged row ----
-        int wfin_b, wfin_e;
-        if (stage_is_a) {
-#pragma unroll
-            for (int k = 0; k < CPT; ++k)
-                pab[k] = (static_cast<double>(sR[pk[k] & 0xffff]) + static_cast<double>(sR[pk[k] >> 16])) * 0.25;
-            wfin_b = wb;
-            wfin_e = (nextB == p.n_prev) ? we : wb;
-        } else {
-            const int ri = dsc.x, orow = dsc.y;
+        int wfin_b = 0, wfin_e = 0;                     // rows without a B source to finish from pab after this stage
+        if (!stage_is_a) {
             float *orowp = p.out + (long long)orow * p.ld;
             // a row with a B source is a new member with both parents: weight 1/2 x 1/2 per column
             const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
@@ -804,15 +824,29 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
                 if (jq < ce) store_row4(orowp, row_bytes, jq * 4u, vq);
             }
             if (dcol >= 0) {
-                const unsigned r = (unsigned)dcol - cb;
-                if ((unsigned)dcol >= cb && (unsigned)dcol < ce && ((r >> 2) & (NT - 1)) == tl)
+                const unsigned rr = (unsigned)dcol - cb;
+                if ((unsigned)dcol >= cb && (unsigned)dcol < ce && ((rr >> 2) & (NT - 1)) == tl)
                     st_off<float>(orowp, (unsigned)dcol * 4u, diag);
             }
             if (CERT) { if (ck < p.cert_thresh) p.cert_out[ri] = 1; }     // plain store: the words only ever go 0 -> 1
-            wfin_b = w + 1;
-            wfin_e = (nextB == p.n_prev) ? we : w + 1;
         }
-        // children without a B source (dragged or one-parent rows): finish from pab alone
+        if (stage_is_a || chain) {
+            // the expansion of the staged row: the hub of this segment (stage A), or -- the row is still in LDS -- of the
+            // NEXT one (chain step: no hub row is staged for it).  ONE site writes pab: a second one inside the loop above
+            // costs ~1.5 VGPRs per column (spills).
+            unsigned z1 = 0, tlg = tl;                  // opaque: nothing of the loop above may be shared with this one
+            asm volatile("" : "+s"(z1));
+            asm volatile("" : "+v"(tlg));
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const unsigned pkk = pk[k] ^ z1;
+                pab[k] = (static_cast<double>(sR[pkk & 0xffff]) + static_cast<double>(sR[pkk >> 16])) * 0.25;
+            }
+            // the (new) hub's rows without B source lead its segment
+            wfin_b = stage_is_a ? wb : nsg.x;
+            wfin_e = wfin_b + (stage_is_a ? n0 : nsg.z);
+        }
+        // rows without a B source (dragged or one-parent rows of the hub): finish from pab alone
         for (int wf = wfin_b; wf < wfin_e; ++wf) {
             unsigned tlf = tl;
             asm volatile("" : "+v"(tlf));
@@ -840,15 +874,23 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         }
 
         // ---- advance the stage state ----
-        if (nextB != p.n_prev) {
-            w = stage_is_a ? wb : w + 1;
+        if (stage_is_a) {
+            w = wb + n0;
+        } else if (w + 1 < we) {
+            w = w + 1;
+        } else if (seg_step) {                          // next segment of the run: hub = the row just staged (type 1) or the same hub (type 2)
+            g = g + 1;
+            if (chain) Ai = Bi;
+            wb = nsg.x; we = n_we; n0 = nsg.z;
+            w = wb + n0;
+        }
+        if (nextB != p.n_prev) {                        // next stage: B row of child w
             stage_is_a = false;
-        } else {
+        } else {                                        // next stage: the first segment of the next item
             if (!have_next) break;
-            it = next_item;
-            g = gn; gk = gkn;
-            chunk = it - gk * p.n_chunks;
-            wb = grp[g].x; we = grp[g + 1].x; Ai = nextAi;
+            const int chunk = nxt_l - rkn * p.n_chunks;
+            g = gn; g_end = run[rn + 1].x;
+            wb = seg[g].x; we = seg[g + 1].x; n0 = seg[g].z; Ai = nextAi;
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
@@ -857,45 +899,48 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
     }
 }
 
-// Splits the sibling groups of one SPLIT launch by certificate, on the device: a group is certified
-// when the A row and the B row of every child carry the certificate (cert_prev == 0).  Certified
-// group indices are appended to list0, the others to list1 (either may be nullptr); cnt[0] / cnt[1]
-// receive their numbers.  The 256 groups of a block stay contiguous and in order (block-level
-// scan, one atomic per block and list), so the planner's reuse order survives up to the order in
-// which the blocks arrive.  `span` != nullptr: the row range that decides is span[g] (the
-// grouping-exact kernel walks halves of the groups of 8 and must own exactly the rows the other
-// kernel does not).
+// Splits the runs of one SPLIT launch (see WalkLists in planner.h) by certificate, on the device: a run is
+// certified when its first hub row and the B row of every one of its work rows carry the certificate
+// (cert_prev == 0; hubs entered by a chain step are B rows).  Certified run indices are appended to list0 -- the
+// items of level_split_fast_kernel; the 32 runs of a block stay contiguous and in order (block-level scan, one
+// atomic per block), so the walk order survives up to the order in which the blocks arrive -- and the SEGMENTS of
+// the other runs to list1, the items of the grouping-exact level_split_kernel.  cnt[0] / cnt[1] = their numbers.
+// Eight lanes per run (its work rows strided over them: a run is up to ~40 rows, and one thread walking them alone
+// costs two dependent loads per row at memory latency: 64 us per level where this takes 5), 32 runs per block.
+constexpr int kSplitLanes = 8, kSplitRuns = 256 / kSplitLanes;
 __global__ void __launch_bounds__(256)
-group_split_kernel(const int4 *__restrict__ desc, const int2 *__restrict__ grp, const int2 *__restrict__ span, int n_groups,
+group_split_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int2 *__restrict__ run, int n_runs,
                    const int *__restrict__ cert_prev, int *__restrict__ list0, int *__restrict__ list1, int *__restrict__ cnt)
 {
-    __shared__ int wsum[4][2];
-    __shared__ int base[2];
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    int bad = 0;
-    const bool live = g < n_groups;
+    __shared__ int good[kSplitRuns];
+    __shared__ int base;
+    const int sub = threadIdx.x % kSplitLanes, lr = threadIdx.x / kSplitLanes;
+    const int r = blockIdx.x * kSplitRuns + lr;
+    const bool live = r < n_runs;
+    int bad = 0, g0 = 0, g1 = 0;
     if (live) {
-        int wb = grp[g].x, we = grp[g + 1].x;
-        if (span) { wb = span[g].x; we = span[g].y; }
-        bad = cert_prev[grp[g].y];                        // "none" (index n_prev) is never flagged
-        for (int w = wb; w < we; ++w) bad |= cert_prev[desc[w].z];
+        g0 = run[r].x; g1 = run[r + 1].x;
+        const int wb = seg[g0].x, we = seg[g1].x;
+        if (sub == 0) bad = cert_prev[run[r].y];          // "none" (index n_prev) is never flagged
+        for (int w = wb + sub; w < we; w += kSplitLanes) bad |= cert_prev[desc[w].z];
     }
-    const unsigned long long m0 = __ballot(live && bad == 0), m1 = __ballot(live && bad != 0);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int r0 = __popcll(m0 & below), r1 = __popcll(m1 & below);
-    if (lane == 0) { wsum[wv][0] = __popcll(m0); wsum[wv][1] = __popcll(m1); }
+#pragma unroll
+    for (int d = 1; d < kSplitLanes; d <<= 1) bad |= __shfl_xor(bad, d);      // (the 8 lanes of a run sit in one wave)
+    if (sub == 0) good[lr] = (live && bad == 0) ? 1 : 0;
     __syncthreads();
-    int o0 = 0, o1 = 0, t0 = 0, t1 = 0;
-    for (int k = 0; k < 4; ++k) {
-        if (k < wv) { o0 += wsum[k][0]; o1 += wsum[k][1]; }
-        t0 += wsum[k][0]; t1 += wsum[k][1];
+    int o0 = 0, t0 = 0;
+    for (int k = 0; k < kSplitRuns; ++k) {
+        if (k < lr) o0 += good[k];
+        t0 += good[k];
     }
-    if (threadIdx.x == 0) { base[0] = atomicAdd(&cnt[0], t0); base[1] = atomicAdd(&cnt[1], t1); }
+    if (threadIdx.x == 0) base = atomicAdd(&cnt[0], t0);
     __syncthreads();
-    if (live) {
-        if (bad == 0) { if (list0) list0[base[0] + o0 + r0] = g; }
-        else          { if (list1) list1[base[1] + o1 + r1] = g; }
+    if (live && sub == 0) {
+        if (bad == 0) list0[base + o0] = r;
+        else {                                            // (rare: kinships below 2^-27 somewhere in the run)
+            const int b1 = atomicAdd(&cnt[1], g1 - g0);
+            for (int g = g0; g < g1; ++g) list1[b1 + g - g0] = g;
+        }
     }
 }
 
@@ -1489,7 +1534,10 @@ constexpr size_t kIdxPad = 32 * 1024;
 struct Tuning {
     int lds_cap_floats = 0;        // GENPHI_LDS_CAP_FLOATS   test: LDS budget for staged rows (forces SPLIT / WIDE on small inputs)
     int full_max_floats = -1;      // GENPHI_FULL_MAX_FLOATS  tuning: FULL vs SPLIT threshold (row length in floats)
-    int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per sibling group of the SPLIT kernels
+    int max_group = 4;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 4)
+    int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
+                                   //                         larger: the walk chains from hub to hub (16-20 % fewer staged rows, measured no faster:
+                                   //                         profiles/microbench/out/r03_ab_hub_walk_*.out)
     int full_bs = 0;               // GENPHI_FULL_BS          tuning: workgroup size of level_full_kernel
     bool no_identity = false;      // GENPHI_NO_IDENTITY      test: level step 0 on a materialised 1/2 I
     int cert_min_exp = -27;        // GENPHI_CERT_MIN_EXP     test: certificate threshold 2^e, e in [-27, 0] (always safe)
@@ -1516,7 +1564,8 @@ static Tuning tuning_from_env()
     auto has = [](const char *name) { return std::getenv(name) != nullptr; };
     t.lds_cap_floats = geti("GENPHI_LDS_CAP_FLOATS", 0);
     t.full_max_floats = geti("GENPHI_FULL_MAX_FLOATS", -1);
-    t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
+    t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 4));
+    t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
     t.no_identity = has("GENPHI_NO_IDENTITY");
     t.cert_min_exp = geti("GENPHI_CERT_MIN_EXP", -27);
@@ -1540,22 +1589,19 @@ static Tuning tuning_from_env()
     return t;
 }
 
-// Sibling groups of a SPLIT work list (rows sorted by (A source, B source); "no B" = n_prev sorts
-// last): runs of equal A source, capped.  Two nested lists over the same row descriptors:
-//   grp   : groups of <= 8 children, walked by level_split_fast_kernel (no per-child state)
-//   grp_s : what level_split_kernel walks.  Where it needs rank masks (cut not in rank order) it
-//           keeps one 32-bit mask per child in 4 VGPRs, so its groups are the halves of the groups
-//           of 8; span_s[g] = work-row range of the enclosing group of 8, whose certificate decides
-//           which kernel owns the rows.  Otherwise grp_s is grp itself (span_s empty).
+// Work lists of a SPLIT launch: the hub walk of planner.h (WalkLists) as device arrays.
+//   desc : per work row (storage row, output row, B source, rank word)
+//   seg  : per segment (first work row, hub row, leading rows without B source, type) + terminators
+//   run  : first segment of every run + terminator
+// level_split_fast_kernel takes runs as its items, level_split_kernel (grouping-exact: it keeps one 32-bit rank
+// mask per child in 4 VGPRs, hence segments of at most 4 children) single segments.
 struct GroupLists {
-    std::vector<int4> desc;    // per work row: (storage row, output row, B source, ord word)
-    std::vector<int2> grp;     // (first work row, A source) + terminator
-    std::vector<int2> grp_s, span_s;
+    genphi::WalkLists w;
 };
 struct DeviceGroups {
-    int4 *desc = nullptr;
-    int2 *grp = nullptr, *grp_s = nullptr, *span_s = nullptr;
-    int n_groups = 0, n_groups_s = 0;
+    int4 *desc = nullptr, *seg = nullptr;
+    int2 *run = nullptr;       // (first segment, hub row of it) per run + terminator
+    int n_segs = 0, n_runs = 0;
 };
 
 struct DeviceStep {
@@ -1570,57 +1616,28 @@ struct DeviceStep {
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
-static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl, int max_group)
+static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl, const Tuning &tun)
 {
-    gl.desc.resize(n_rows);
-    gl.grp.clear(); gl.grp_s.clear(); gl.span_s.clear();
-    // groups are capped: a workgroup walks a group's children one after the other, so one huge
-    // group (e.g. all parentless rows share "no A source") would be a serial tail
-    const int cap = max_group;
-    const int cap_s = s.pos_ord ? cap : std::min(cap, 4);
-    int lastA = -1;
-    for (int w = 0; w < n_rows; ++w) {
-        const int i = rows[w];
-        gl.desc[w] = make_int4(i, out_rows ? out_rows[w] : i, s.srcB[i], s.ord[i]);
-        if (w == 0 || s.srcA[i] != lastA || w - gl.grp.back().x >= cap) {
-            gl.grp.push_back(make_int2(w, s.srcA[i]));
-            lastA = s.srcA[i];
-        }
-    }
-    gl.grp.push_back(make_int2(n_rows, 0));
-    if (cap_s != cap) {
-        const int ng = static_cast<int>(gl.grp.size()) - 1;
-        for (int g = 0; g < ng; ++g) {
-            const int wb = gl.grp[g].x, we = gl.grp[g + 1].x;
-            for (int w = wb; w < we; w += cap_s) {
-                gl.grp_s.push_back(make_int2(w, gl.grp[g].y));
-                gl.span_s.push_back(make_int2(wb, we));
-            }
-        }
-        gl.grp_s.push_back(make_int2(n_rows, 0));
-    }
+    // segments are capped (<= 4 children: the grouping-exact kernel's rank masks) and so are runs: a workgroup
+    // walks a run's stages one after the other, so one huge run would be a serial tail
+    genphi::build_hub_walk(s.srcA.data(), s.srcB.data(), s.ord.data(), static_cast<int32_t>(s.n_prev), rows, out_rows, n_rows,
+                           std::min(tun.max_group, 4), tun.max_run, gl.w);
 }
 
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 static size_t groups_bytes(const GroupLists &gl)
 {
-    return al256(gl.desc.size() * sizeof(int4)) + al256(gl.grp.size() * sizeof(int2)) + al256(gl.grp_s.size() * sizeof(int2)) +
-           al256(gl.span_s.size() * sizeof(int2));
+    return al256(gl.w.desc4.size() * sizeof(int)) + al256(gl.w.seg4.size() * sizeof(int)) + al256(gl.w.run.size() * sizeof(int));
 }
 // put(src, bytes) copies into the host image of a device blob and returns the device address
 template <class Put>
 static void put_groups(const GroupLists &gl, DeviceGroups &d, Put &&put)
 {
-    d.desc = reinterpret_cast<int4 *>(put(gl.desc.data(), gl.desc.size() * sizeof(int4)));
-    d.grp = reinterpret_cast<int2 *>(put(gl.grp.data(), gl.grp.size() * sizeof(int2)));
-    d.n_groups = static_cast<int>(gl.grp.size()) - 1;
-    if (!gl.grp_s.empty()) {
-        d.grp_s = reinterpret_cast<int2 *>(put(gl.grp_s.data(), gl.grp_s.size() * sizeof(int2)));
-        d.span_s = reinterpret_cast<int2 *>(put(gl.span_s.data(), gl.span_s.size() * sizeof(int2)));
-        d.n_groups_s = static_cast<int>(gl.grp_s.size()) - 1;
-    } else {
-        d.grp_s = d.grp; d.span_s = nullptr; d.n_groups_s = d.n_groups;
-    }
+    d.desc = reinterpret_cast<int4 *>(put(gl.w.desc4.data(), gl.w.desc4.size() * sizeof(int)));
+    d.seg = reinterpret_cast<int4 *>(put(gl.w.seg4.data(), gl.w.seg4.size() * sizeof(int)));
+    d.run = reinterpret_cast<int2 *>(put(gl.w.run.data(), gl.w.run.size() * sizeof(int)));
+    d.n_segs = static_cast<int>(gl.w.seg4.size() / 4) - 2;
+    d.n_runs = static_cast<int>(gl.w.run.size() / 2) - 1;
 }
 
 struct genphi_plan {
@@ -1789,6 +1806,24 @@ int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info)
 }
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
 
+int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows, int64_t *n_segs, int64_t *n_runs, int32_t *desc4,
+                          int32_t *seg4, int32_t *run2)
+{
+    if (!plan || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size()))
+        return fail(GENPHI_ERR_ARG, "genphi_plan_step_walk: bad argument");
+    const LevelStep &s = plan->plan.steps[step];
+    if (s.mode != genphi::kModeSplit) return fail(GENPHI_ERR_ARG, "genphi_plan_step_walk: not a SPLIT step");
+    GroupLists gl;
+    build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), gl, plan->tun);
+    if (n_rows) *n_rows = static_cast<int64_t>(gl.w.desc4.size() / 4);
+    if (n_segs) *n_segs = static_cast<int64_t>(gl.w.seg4.size() / 4) - 2;
+    if (n_runs) *n_runs = static_cast<int64_t>(gl.w.run.size() / 2) - 1;
+    if (desc4) std::memcpy(desc4, gl.w.desc4.data(), gl.w.desc4.size() * sizeof(int32_t));
+    if (seg4) std::memcpy(seg4, gl.w.seg4.data(), gl.w.seg4.size() * sizeof(int32_t));
+    if (run2) std::memcpy(run2, gl.w.run.data(), gl.w.run.size() * sizeof(int32_t));
+    return GENPHI_OK;
+}
+
 int genphi_plan_release_device(genphi_plan *plan)
 {
     if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
@@ -1848,7 +1883,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         const LevelStep &s = step_at(k);
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
         if (s.mode == genphi::kModeSplit) {
-            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k], p->tun.max_group);
+            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k], p->tun);
             total += groups_bytes(step_groups[k]);
         }
         if (s.mode == genphi::kModeWide)
@@ -2047,7 +2082,7 @@ static hipError_t set_max_lds(const void *fn, size_t bytes)
 // ---- SPLIT kernel instantiation table ---------------------------------------------------------
 template <int C, int S, bool O>
 static hipError_t launch_split_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
-                                    const int2 *grp, int *queue)
+                                    const int4 *grp, int *queue)
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_kernel<1024, C, S, O>), lds);
     if (e != hipSuccess) return e;
@@ -2057,7 +2092,7 @@ static hipError_t launch_split_inst(int grid, size_t lds, hipStream_t stream, co
 
 template <bool O>
 static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
-                               const int4 *desc, const int2 *grp, int *queue)
+                               const int4 *desc, const int4 *grp, int *queue)
 {
 #define GENPHI_T(C, S) if (cpt <= C && stg == S) return launch_split_inst<C, S, O>(grid, lds, stream, a, desc, grp, queue)
 #ifdef GENPHI_MIN_INST
@@ -2079,11 +2114,11 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
 // holds ~25 % more columns -- 4 column chunks instead of 5 for the 1e5-wide final level of cfg4)
 template <int NT, int C, int S, bool CERT>
 static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
-                                   const int2 *grp, int *queue)
+                                   const int4 *grp, const int2 *run, int *queue)
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, a.glist, queue);
+    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, run, a.glist, queue);
     return hipGetLastError();
 }
 
@@ -2097,9 +2132,9 @@ static int fast_max_cpt(int nt, int stg)
 
 template <bool CERT>
 static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
-                              const int4 *desc, const int2 *grp, int *queue)
+                              const int4 *desc, const int4 *grp, const int2 *run, int *queue)
 {
-#define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT>(grid, lds, stream, a, desc, grp, queue)
+#define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT>(grid, lds, stream, a, desc, grp, run, queue)
 #ifdef GENPHI_MIN_INST
     GENPHI_F(1024, 16, 2); GENPHI_F(1024, 24, 8); GENPHI_F(512, 56, 16);
 #else
@@ -2225,7 +2260,7 @@ static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, 
         if (env_cpt >= 4) max_cpt = std::min(max_cpt, env_cpt / 4 * 4);
         const int n_chunks = (per_thread + max_cpt - 1) / max_cpt;
         const int cpt = (per_thread + n_chunks - 1) / n_chunks;
-        const long long n_items = static_cast<long long>(dg.n_groups_s) * n_chunks;
+        const long long n_items = static_cast<long long>(dg.n_segs) * n_chunks;
         if (certs) {
             // ---- certified groups: level_split_fast_kernel ----
             LevelArgs f = a;
@@ -2243,22 +2278,12 @@ static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, 
             }
             const int f_pt = static_cast<int>((width + f_nt - 1) / f_nt);
             const int f_cpt = ((f_pt + f_chunks - 1) / f_chunks + 3) / 4 * 4;
-            const long long f_items = static_cast<long long>(dg.n_groups) * f_chunks;
-            // certified groups -> glist_f / gcnt[0], the others (in the grouping-exact kernel's own
-            // group list) -> glist_s / gcnt[3]: decided on the device, per launch
+            const long long f_items = static_cast<long long>(dg.n_runs) * f_chunks;
+            // certified runs -> glist_f / gcnt[0], the segments of the others -> glist_s / gcnt[1]: decided on the device, per launch
             int *glist_f = R.glist_f, *glist_s = R.glist_s;
-            int *gcnt_s = gcnt;                                               // [1] = groups of the grouping-exact kernel
-            if (dg.span_s) {
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp,
-                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, static_cast<int *>(nullptr), gcnt);
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups_s + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp_s,
-                                   static_cast<const int2 *>(dg.span_s), dg.n_groups_s, a.cert_prev, static_cast<int *>(nullptr), glist_s,
-                                   gcnt + 2);
-                gcnt_s = gcnt + 2;
-            } else {                                                          // both kernels walk the same group list: one pass
-                hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_groups + 255) / 256), dim3(256), 0, R.stream, dg.desc, dg.grp,
-                                   static_cast<const int2 *>(nullptr), dg.n_groups, a.cert_prev, glist_f, glist_s, gcnt);
-            }
+            int *gcnt_s = gcnt;                                               // [1] = segments of the grouping-exact kernel
+            hipLaunchKernelGGL(group_split_kernel, dim3((dg.n_runs + kSplitRuns - 1) / kSplitRuns), dim3(256), 0, R.stream, dg.desc, dg.seg, dg.run, dg.n_runs,
+                               a.cert_prev, glist_f, glist_s, gcnt);
             HIP_TRY(hipGetLastError());
             f.glist = glist_f; f.gcnt = gcnt;
             f.chunk_magic = chunk_magic_for(f_chunks);
@@ -2266,10 +2291,10 @@ static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, 
             f.slot_off = static_cast<int>(f_lds_stage / sizeof(float));
             f.chunk_cols = f_cpt * f_nt;
             f.n_chunks = f_chunks;
-            f.n_groups = dg.n_groups;
+            f.n_groups = dg.n_runs;
             const int f_grid = static_cast<int>(std::min<long long>(R.n_cus, (f_items + 7) / 8 * 8));
-            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.grp, queue)
-                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.grp, queue));
+            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue)
+                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue));
             a.zero_row = 0;                                                   // the fast launch wrote the "none" row
             a.glist = glist_s; a.gcnt = gcnt_s;
         }
@@ -2278,10 +2303,10 @@ static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, 
         a.chunk_cols = (cpt + 3) / 4 * 4 * nt_s;                        // whole quads of columns per thread
         a.n_chunks = n_chunks;
         a.chunk_magic = chunk_magic_for(n_chunks);
-        a.n_groups = dg.n_groups_s;
+        a.n_groups = dg.n_segs;
         const int grid = static_cast<int>(std::min<long long>(R.n_cus, (n_items + 7) / 8 * 8));   // persistent: one workgroup per CU
-        HIP_TRY(pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.grp_s, queue + 8)
-                          : launch_split<false>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.grp_s, queue + 8));
+        HIP_TRY(pos_ord ? launch_split<true>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.seg, queue + 8)
+                          : launch_split<false>(cpt, stg_inst, grid, lds, R.stream, a, dg.desc, dg.seg, queue + 8));
     } else {
         return fail(GENPHI_ERR_ARG, "internal: launch_rows takes FULL and SPLIT steps");
     }
@@ -2361,8 +2386,8 @@ int genphi::launch_panel_level(const PanelLaunch &L)
     R.queue = L.counters; R.gcnt = L.counters + 16;
     R.glist_f = L.glist; R.glist_s = L.glist + L.glist_cap;
     DeviceGroups dg;
-    dg.desc = const_cast<int4 *>(L.desc); dg.grp = const_cast<int2 *>(L.grp); dg.grp_s = dg.grp; dg.span_s = nullptr;
-    dg.n_groups = dg.n_groups_s = L.n_groups;
+    dg.desc = const_cast<int4 *>(L.desc); dg.seg = const_cast<int4 *>(L.seg); dg.run = const_cast<int2 *>(L.run);
+    dg.n_segs = L.n_segs; dg.n_runs = L.n_runs;
     return launch_rows(R, a, L.mode, /*pos_ord=*/false, L.src_width, L.ld, /*kernel=*/0, dg);
 }
 
@@ -2648,7 +2673,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         std::vector<char> gimg;
         if (n_steps > 0 && pl.steps[n_steps - 1].mode == genphi::kModeSplit) {
             GroupLists gl;
-            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl, p->tun.max_group);
+            build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl, p->tun);
             const size_t gb = groups_bytes(gl);
             if (gb > p->shard_blob_bytes) {
                 if (p->d_shard_blob) { HIP_TRY(hipFree(p->d_shard_blob)); p->d_shard_blob = nullptr; p->shard_blob_bytes = 0; }
@@ -2706,7 +2731,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         if (sv.srcB[i] < sv.n_prev) need_prev[sv.srcB[i]] = 1;
                     }
                 if (sv.mode == genphi::kModeSplit) {
-                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_gl[st], p->tun.max_group);
+                    build_groups(sv, rw.data(), nullptr, static_cast<int>(rw.size()), host_gl[st], p->tun);
                     total += groups_bytes(host_gl[st]);
                 }
                 total += al(rw.size() * sizeof(int));
@@ -2725,7 +2750,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 genphi_plan::ShardStep &sh = p->sh_steps[st];
                 sh.n_rows = static_cast<int>(host_rows[st].size());
                 sh.rows = reinterpret_cast<int *>(put(host_rows[st].data(), host_rows[st].size() * sizeof(int)));
-                if (!host_gl[st].grp.empty()) put_groups(host_gl[st], sh.groups, put);
+                if (!host_gl[st].w.run.empty()) put_groups(host_gl[st], sh.groups, put);
             }
             HIP_TRY(hipMemcpyAsync(p->sh_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
             HIP_TRY(hipStreamSynchronize(p->stream));

@@ -29,10 +29,11 @@ struct PanelLaunch {
     const int *diag_col;         // per row: its local column, or -1
     const int *work;             // rows in work order (rows sharing the A source adjacent), n_cut entries
     int mode;                    // 0 FULL, 1 SPLIT
-    const int4 *desc;            // SPLIT: per work row (row, row, B source, rank word)
-    const int2 *grp;             // SPLIT: (first work row, A source) per sibling group + terminator
-    const int2 *pdesc;           // SPLIT: per work row (local column or -1, panel column of the A source)
-    int n_groups;
+    const int4 *desc;            // SPLIT: the hub walk of the cut's rows (WalkLists, planner.h): per work row (row, row, B source, rank word)
+    const int4 *seg;             // SPLIT: per segment (first work row, hub row, leading rows without B source, type) + terminators
+    const int2 *run;             // SPLIT: (first segment, its hub row) of every run + terminator
+    const int2 *pdesc;           // SPLIT: per work row (local column or -1, panel column of the member's OTHER source: the hub of its segment)
+    int n_segs, n_runs;
     const int *cert_prev;        // exactness certificates of the rows of psi (this rank's columns of them)
     int *cert_out;               // ... of the rows written (zeroed by the caller)
     int *counters;               // 20 ints (work queues + group counts), zeroed by launch_panel_level

@@ -159,16 +159,16 @@ struct PanelStep {
     std::vector<int> ord_col;                  // rank word per local column (+ padding)
     std::vector<int> diag_col;                 // per row of the cut: its local column or -1
     std::vector<int> work;                     // rows sorted by (A source, B source)
-    std::vector<int4> desc;                    // SPLIT
-    std::vector<int2> grp, pdesc;
-    int n_groups = 0;
+    genphi::WalkLists walk;                    // SPLIT: the hub walk of the cut's rows
+    std::vector<int2> pdesc;
+    int n_segs = 0, n_runs = 0;
 };
 
 struct DevPanelStep {
     unsigned *pk_col = nullptr;
     int *ord_col = nullptr, *diag_col = nullptr, *work = nullptr;
-    int4 *desc = nullptr;
-    int2 *grp = nullptr, *pdesc = nullptr;
+    int4 *desc = nullptr, *seg = nullptr;
+    int2 *run = nullptr, *pdesc = nullptr;
 };
 
 }  // namespace
@@ -210,7 +210,7 @@ static void panel_free_device(genphi_panel *p)
     rel(p->panel[0]); rel(p->panel[1]); rel(p->result);
     rel(p->d_cert[0]); rel(p->d_cert[1]); rel(p->d_counters); rel(p->d_glist);
     for (hipEvent_t &e : p->ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    for (DevPanelStep &d : p->d_step) { rel(d.pk_col); rel(d.ord_col); rel(d.diag_col); rel(d.work); rel(d.desc); rel(d.grp); rel(d.pdesc); }
+    for (DevPanelStep &d : p->d_step) { rel(d.pk_col); rel(d.ord_col); rel(d.diag_col); rel(d.work); rel(d.desc); rel(d.seg); rel(d.run); rel(d.pdesc); }
     p->d_step.clear();
     p->panel_floats[0] = p->panel_floats[1] = 0;
     for (auto &v : {&p->d_srcA, &p->d_srcB, &p->d_ord, &p->d_send_cols, &p->d_member}) { for (int *&q : *v) rel(q); v->clear(); }
@@ -361,18 +361,20 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
                 return st.srcA[x] != st.srcA[y] ? st.srcA[x] < st.srcA[y] : st.srcB[x] < st.srcB[y];     // "no B" = n_prev sorts last
             });
             if (ps.mode == 1) {
-                // sibling groups: runs of equal A source, at most 4 children (the grouping-exact kernel keeps one rank mask per child)
-                ps.desc.resize(st.n); ps.pdesc.resize(st.n);
-                int lastA = -1;
-                for (int w = 0; w < static_cast<int>(st.n); ++w) {
-                    const int i = ps.work[w];
-                    ps.desc[w] = make_int4(i, i, st.srcB[i], st.ord[i]);
-                    const int dcol = ps.diag_col[i];
-                    ps.pdesc[w] = make_int2(dcol, dcol >= 0 ? static_cast<int>(ps.pk_col[dcol] & 0xffff) : zcol);
-                    if (w == 0 || st.srcA[i] != lastA || w - ps.grp.back().x >= 4) { ps.grp.push_back(make_int2(w, st.srcA[i])); lastA = st.srcA[i]; }
+                // the hub walk of the cut's rows (planner.h), and per work row where the member's own column is and which
+                // panel column holds its OTHER source (the hub of its segment: the staged row is the B source, and the
+                // self kinship 1/2 + Psi[B][hub]/2 is read from it)
+                genphi::build_hub_walk(st.srcA.data(), st.srcB.data(), st.ord.data(), n_prev, ps.work.data(), nullptr, static_cast<int>(st.n), 4, 1, ps.walk);
+                ps.n_segs = static_cast<int>(ps.walk.seg4.size() / 4) - 2;
+                ps.n_runs = static_cast<int>(ps.walk.run.size() / 2) - 1;
+                ps.pdesc.resize(st.n);
+                for (int g = 0; g < ps.n_segs; ++g) {
+                    const int hub = ps.walk.seg4[4 * g + 1];
+                    for (int w = ps.walk.seg4[4 * g]; w < ps.walk.seg4[4 * (g + 1)]; ++w) {
+                        const int i = ps.walk.desc4[4 * w];
+                        ps.pdesc[w] = make_int2(ps.diag_col[i], ps.diag_col[i] >= 0 ? ext_of[hub] : zcol);
+                    }
                 }
-                ps.n_groups = static_cast<int>(ps.grp.size());
-                ps.grp.push_back(make_int2(static_cast<int>(st.n), 0));
             }
         }
     }
@@ -430,7 +432,7 @@ double genphi_panel_device_bytes(const genphi_panel *p)
         const PanelStep &ps = p->steps[c];
         bytes += 12.0 * static_cast<double>(p->plan.steps[c].n) + 4.0 * static_cast<double>(ps.send_cols.size()) + 16.0 * static_cast<double>(ps.col.size());
         bytes += 4.0 * static_cast<double>(ps.pk_col.size() + ps.ord_col.size() + ps.diag_col.size() + ps.work.size()) +
-                 16.0 * static_cast<double>(ps.desc.size()) + 8.0 * static_cast<double>(ps.grp.size() + ps.pdesc.size());
+                 4.0 * static_cast<double>(ps.walk.desc4.size() + ps.walk.seg4.size() + ps.walk.run.size()) + 8.0 * static_cast<double>(ps.pdesc.size());
     }
     return bytes;
 }
@@ -503,8 +505,9 @@ static int panel_upload_impl(genphi_panel *p, int device)
         PN_TRY(up(ps.diag_col.data(), ps.diag_col.size() * sizeof(int), reinterpret_cast<void **>(&d.diag_col)));
         PN_TRY(up(ps.work.data(), ps.work.size() * sizeof(int), reinterpret_cast<void **>(&d.work)));
         if (ps.mode == 1) {
-            PN_TRY(up(ps.desc.data(), ps.desc.size() * sizeof(int4), reinterpret_cast<void **>(&d.desc)));
-            PN_TRY(up(ps.grp.data(), ps.grp.size() * sizeof(int2), reinterpret_cast<void **>(&d.grp)));
+            PN_TRY(up(ps.walk.desc4.data(), ps.walk.desc4.size() * sizeof(int), reinterpret_cast<void **>(&d.desc)));
+            PN_TRY(up(ps.walk.seg4.data(), ps.walk.seg4.size() * sizeof(int), reinterpret_cast<void **>(&d.seg)));
+            PN_TRY(up(ps.walk.run.data(), ps.walk.run.size() * sizeof(int), reinterpret_cast<void **>(&d.run)));
             PN_TRY(up(ps.pdesc.data(), ps.pdesc.size() * sizeof(int2), reinterpret_cast<void **>(&d.pdesc)));
         }
     }
@@ -604,7 +607,7 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
         L.n_prev = n_prev; L.n_cut = n; L.n_cols = ps.n_cols; L.src_width = ps.src_width;
         L.srcA = p->d_srcA[step]; L.srcB = p->d_srcB[step]; L.ord = p->d_ord[step];
         L.pk_col = d.pk_col; L.ord_col = d.ord_col; L.diag_col = d.diag_col; L.work = d.work;
-        L.mode = ps.mode; L.desc = d.desc; L.grp = d.grp; L.pdesc = d.pdesc; L.n_groups = ps.n_groups;
+        L.mode = ps.mode; L.desc = d.desc; L.seg = d.seg; L.run = d.run; L.pdesc = d.pdesc; L.n_segs = ps.n_segs; L.n_runs = ps.n_runs;
         L.cert_prev = p->d_cert[step & 1]; L.cert_out = cert_out;
         L.counters = p->d_counters; L.glist = p->d_glist; L.glist_cap = p->glist_cap;
         const int rc = genphi::launch_panel_level(L);

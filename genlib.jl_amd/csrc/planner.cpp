@@ -182,6 +182,97 @@ void reuse_order(const LevelStep &st, std::vector<int32_t> &rows)
     reuse_order_impl(st, rows, w);
 }
 
+void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord, int32_t none, const int *rows,
+                    const int *out_rows, int n_rows, int seg_cap, int max_run, WalkLists &out)
+{
+    out.desc4.clear(); out.seg4.clear(); out.run.clear(); out.row_k.clear();
+    out.desc4.reserve(static_cast<size_t>(n_rows) * 4);
+    out.row_k.reserve(n_rows);
+    seg_cap = std::max(1, seg_cap);
+    max_run = std::max(1, max_run);
+    // adjacency (CSR) over the nodes 0 .. none: a row is listed at its A source and, when it has one, at its B source
+    // (A == none only for parentless members, whose hub is the all-zero row; A == B, selfing, is listed once)
+    std::vector<int32_t> start(static_cast<size_t>(none) + 2, 0);
+    for (int k = 0; k < n_rows; ++k) {
+        const int i = rows[k];
+        start[srcA[i] + 1]++;
+        if (srcB[i] != none && srcB[i] != srcA[i]) start[srcB[i] + 1]++;
+    }
+    for (int32_t v = 0; v <= none; ++v) start[v + 1] += start[v];
+    std::vector<int32_t> adj(start[none + 1]), fill(start.begin(), start.end() - 1), ptr(start.begin(), start.end() - 1);
+    for (int k = 0; k < n_rows; ++k) {
+        const int i = rows[k];
+        adj[fill[srcA[i]]++] = k;
+        if (srcB[i] != none && srcB[i] != srcA[i]) adj[fill[srcB[i]]++] = k;
+    }
+    std::vector<char> done(n_rows, 0);
+    auto has_work = [&](int32_t v) {
+        while (ptr[v] < start[v + 1] && done[adj[ptr[v]]]) ++ptr[v];
+        return ptr[v] < start[v + 1];
+    };
+    auto put_row = [&](int k, int32_t b_src) {
+        const int i = rows[k];
+        out.desc4.push_back(i); out.desc4.push_back(out_rows ? out_rows[k] : i); out.desc4.push_back(b_src); out.desc4.push_back(ord[i]);
+        out.row_k.push_back(k);
+    };
+    std::vector<int32_t> singles, edges, spill;                 // spill: (hub, row) pairs of rows without B source beyond kMaxSingles per hub visit
+    constexpr size_t kMaxSingles = 8;                           // a workgroup finishes them one after the other: all parentless members of a cut
+                                                                // share the hub "none", and hundreds of them in one run would be a serial tail
+    for (int k0 = 0; k0 < n_rows; ++k0) {
+        if (done[k0]) continue;
+        int32_t hub = srcA[rows[k0]];
+        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);
+        int type = 0, stages = 1;                               // (the staged hub row of the run's first segment)
+        for (;;) {
+            singles.clear(); edges.clear();
+            for (int32_t t = ptr[hub]; t < start[hub + 1]; ++t) {
+                const int k = adj[t];
+                if (done[k]) continue;
+                done[k] = 1;
+                (srcB[rows[k]] == none ? singles : edges).push_back(k);
+            }
+            ptr[hub] = start[hub + 1];
+            while (singles.size() > kMaxSingles) { spill.push_back(hub); spill.push_back(singles.back()); singles.pop_back(); }
+            auto other = [&](int k) { const int i = rows[k]; return srcA[i] == hub ? srcB[i] : srcA[i]; };
+            // the child whose other parent still has work goes last: its stage yields the next hub's expansion
+            int32_t next_hub = -1;
+            for (size_t e = edges.size(); e-- > 0;) {
+                const int32_t o = other(edges[e]);
+                if (o != hub && has_work(o)) { next_hub = o; std::swap(edges[e], edges.back()); break; }
+            }
+            size_t e = 0;
+            bool first = true;
+            do {                                                // segments of this hub: its rows without B source lead the first one
+                const size_t m = std::min(edges.size() - e, static_cast<size_t>(seg_cap));
+                out.seg4.push_back(static_cast<int32_t>(out.desc4.size() / 4)); out.seg4.push_back(hub);
+                out.seg4.push_back(first ? static_cast<int32_t>(singles.size()) : 0); out.seg4.push_back(first ? type : 2);
+                if (first) for (int32_t k : singles) put_row(k, none);
+                for (size_t q = 0; q < m; ++q) put_row(edges[e + q], other(edges[e + q]));
+                e += m;
+                first = false;
+            } while (e < edges.size());
+            stages += static_cast<int>(edges.size());
+            if (next_hub < 0 || stages >= max_run) break;
+            hub = next_hub;
+            type = 1;
+        }
+    }
+    // the rows without B source that exceeded a hub visit's share: runs of their own (the hub row staged again, up to
+    // kMaxSingles rows finished from it)
+    for (size_t q = 0; q < spill.size();) {
+        const int32_t hub = spill[q];
+        size_t e = q;
+        while (e < spill.size() && spill[e] == hub && (e - q) / 2 < kMaxSingles) e += 2;
+        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);
+        out.seg4.push_back(static_cast<int32_t>(out.desc4.size() / 4)); out.seg4.push_back(hub);
+        out.seg4.push_back(static_cast<int32_t>((e - q) / 2)); out.seg4.push_back(0);
+        for (; q < e; q += 2) put_row(spill[q + 1], none);
+    }
+    out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(0);
+    out.seg4.push_back(n_rows); out.seg4.push_back(0); out.seg4.push_back(0); out.seg4.push_back(0);       // terminator (two, so that seg[g + 2] is readable)
+    out.seg4.push_back(n_rows); out.seg4.push_back(0); out.seg4.push_back(0); out.seg4.push_back(0);
+}
+
 int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
                int64_t n_pro, const int64_t *pro_ids, const PlanOptions &opt, Plan &plan,
                std::string &err)

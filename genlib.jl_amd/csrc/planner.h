@@ -101,6 +101,28 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
 // L2 / the Infinity Cache instead of HBM.
 void reuse_order(const LevelStep &step, std::vector<int32_t> &rows);
 
+// Work lists of a SPLIT launch: a HUB WALK over the parent graph of the launch's rows.
+// A row with two sources (A, B) is an edge between the rows A and B of the previous level.  A workgroup that
+// holds the expansion of a "hub" row H in registers (per column j: (Psi[H][A_j] + Psi[H][B_j]) / 4) finishes
+//   - the rows whose only source is H (the dragged member H itself, one-parent children) from it alone,
+//   - every child (H, X) by staging row X:  out = RN32(expansion(H) + expansion(X)),
+// and the expansion of the LAST such X is a by-product of its stage, so the walk goes on with X as the hub
+// without staging a hub row again.  A RUN is such a walk (an item of the kernels' work queue), cut into SEGMENTS
+// of one hub and at most `seg_cap` children with a B source:
+//   desc4[4 w ..]  = (storage row, output row, B source (= the row to stage; none: finished from the hub alone), rank word)
+//   seg4[4 g ..]   = (first work row, hub row, number of leading work rows without B source, type)  + a terminator
+//                    type 0: the run starts here (the hub row is staged), 1: the hub is the B row of the previous
+//                    segment's last child (its expansion is already in registers), 2: same hub as the previous segment
+//   run[2 r ..]    = (first segment of run r, its hub row)  + a terminator
+// Random mating (every member about two children): ~16 % fewer staged rows per level than one group per father;
+// the 1e5-wide last level of cfg4: ~12 % fewer.  The order of the start rows follows `rows` (the planner's reuse order).
+struct WalkLists {
+    std::vector<int32_t> desc4, seg4, run;
+    std::vector<int32_t> row_k;        // per work row: its index in `rows`
+};
+void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord, int32_t none, const int *rows,
+                    const int *out_rows, int n_rows, int seg_cap, int max_run, WalkLists &out);
+
 inline int64_t pitch_for(int64_t n) { return ((n + 1) + 63) / 64 * 64; }
 
 }  // namespace genphi

@@ -118,11 +118,11 @@ sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__rest
     }
     *reinterpret_cast<float4 *>(trow + q0) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (q0 + u >= n_old) break;
-        if (np[u] >= 0) orow[np[u]] = v[u];
+    for (int u = 0; u < 4; ++u) {                                    // (no early exit: the arrays must stay in registers)
+        const bool live = q0 + u < n_old;
+        if (live && np[u] >= 0) orow[np[u]] = v[u];
         // phi[rank_q][rank_i] outlives i's retirement when q is a proband with the larger rank (i a non-proband)
-        if (v[u] > 0.f && !(mi.x & 1) && (mq[u].x & 1) && mq[u].x > mi.x) stale_append(so, mq[u].x >> 1, mi.x >> 1, v[u]);
+        if (live && v[u] > 0.f && !(mi.x & 1) && (mq[u].x & 1) && mq[u].x > mi.x) stale_append(so, mq[u].x >> 1, mi.x >> 1, v[u]);
     }
 }
 
@@ -185,7 +185,7 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int b = b0 + u * 256;
-            if (b >= n_new) break;
+            if (b >= n_new) continue;
             // the parents left the queue before a (an earlier wave): T[a][parent] sits under (rank parent, rank a),
             // which the lookup (smaller rank, larger rank) finds only when rank parent < rank a
             const float tf = (p[u].x != n_old && p[u].z < ma.x) ? src[p[u].x] : 0.f;

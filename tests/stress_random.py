@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
-         "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE"]
+         "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN"]
 
 
 def main():
@@ -57,6 +57,8 @@ def main():
             env["GENPHI_MAX_GROUP"] = str(int(r.choice([1, 3, 8])))
         if r.random() < 0.5:
             env["GENPHI_WIDE_ROUTE"] = str(r.choice(["A", "B"]))
+        if r.random() < 0.5:
+            env["GENPHI_MAX_RUN"] = str(int(r.choice([2, 7, 32, 1000])))             # hub walk with chain steps
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)

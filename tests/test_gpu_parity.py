@@ -626,8 +626,11 @@ def test_certified_rows_fast_path_and_mixed_levels(gen, oracle, monkeypatch):
             monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
             for env in ({}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_CERT_MIN_EXP": "-9"}, {"GENPHI_CERT_MIN_EXP": "-4"},
                         {"GENPHI_CERT_MIN_EXP": "-1"}, {"GENPHI_FAST_NT": "512"}, {"GENPHI_FAST_NT": "512", "GENPHI_CERT_MIN_EXP": "-5"},
-                        {"GENPHI_MAX_CPT": "8", "GENPHI_CERT_MIN_EXP": "-6"}, {"GENPHI_FAST_NT": "512", "GENPHI_MAX_CPT": "4"}):
-                for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_MAX_CPT"):
+                        {"GENPHI_MAX_CPT": "8", "GENPHI_CERT_MIN_EXP": "-6"}, {"GENPHI_FAST_NT": "512", "GENPHI_MAX_CPT": "4"},
+                        # the hub walk chaining from hub to hub (runs of several segments, chain steps), certified and mixed
+                        {"GENPHI_MAX_RUN": "32"}, {"GENPHI_MAX_RUN": "6", "GENPHI_CERT_MIN_EXP": "-5"},
+                        {"GENPHI_MAX_RUN": "100", "GENPHI_FAST_NT": "512", "GENPHI_MAX_GROUP": "2"}):
+                for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_MAX_CPT", "GENPHI_MAX_RUN", "GENPHI_MAX_GROUP"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -639,7 +642,7 @@ def test_certified_rows_fast_path_and_mixed_levels(gen, oracle, monkeypatch):
                 _assert_equal(np.concatenate(parts, axis=0), want)
                 pl.close()
     for k in ("GENPHI_NO_FAST", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_MAX_CPT", "GENPHI_FULL_MAX_FLOATS",
-              "GENPHI_NO_SMALL", "GENPHI_LDS_CAP_FLOATS"):
+              "GENPHI_NO_SMALL", "GENPHI_LDS_CAP_FLOATS", "GENPHI_MAX_RUN", "GENPHI_MAX_GROUP"):
         monkeypatch.delenv(k, raising=False)
     # genea140 (real pedigree, kinships down to 2^-35: some rows are not certified), default geometry
     ped = gen.genealogy(gen.genea140)

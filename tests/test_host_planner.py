@@ -245,3 +245,64 @@ def test_c_abi_from_plain_c_on_gpu(gen, tmp_path):
     assert rows == [[0.591796875, 0.37109375, 0.072265625], [0.37109375, 0.591796875, 0.072265625],
                     [0.072265625, 0.072265625, 0.53515625]]                 # test/runtests.jl:50-52
     assert out[10] == "phiMean 0.171875"                                       # :53
+
+
+def test_hub_walk_work_lists(monkeypatch):
+    """The work lists of the SPLIT kernels (csrc/planner.h, build_hub_walk): a walk over the parent graph of a cut's
+    rows in which a workgroup keeps the expansion of one "hub" row in registers, finishes the rows that have only that
+    source from it, stages the OTHER parent's row of every child, and goes on with the row staged last as the next hub.
+    Invariants the kernels rely on, and the point of it: fewer staged rows than one group per father."""
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    monkeypatch.setenv("GENPHI_FULL_MAX_FLOATS", "0")                       # every level SPLIT
+    for args, kw in [((6000, 700, 7), dict(skip_permille=30)), ((3000, 300, 12), dict(skip_permille=150, seed=11)), ((40_000, 4000, 10), dict())]:
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        if kw.get("seed") == 11:
+            mo = mo.copy(); mo[::17] = 0                                    # one-parent members
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        for max_run in ("32", None, "5"):                                   # (None: the default = 1, no chaining)
+            if max_run is None:
+                monkeypatch.delenv("GENPHI_MAX_RUN", raising=False)
+            else:
+                monkeypatch.setenv("GENPHI_MAX_RUN", max_run)
+            pl = gen.plan(ped, pro)
+            sizes, both = pl.levels()
+            staged_walk = staged_groups = 0
+            for step, mode in enumerate(pl.step_modes()):
+                if mode != 1:
+                    continue
+                desc, seg, run = pl.step_walk(step)
+                n_prev, n = sizes[step], sizes[step + 1]
+                none = n_prev
+                assert sorted(desc[:, 0].tolist()) == list(range(n))                      # every row of the cut exactly once
+                assert np.array_equal(desc[:, 0], desc[:, 1])                            # (no shard: output row = storage row)
+                n_segs, n_runs = len(seg) - 2, len(run) - 1
+                assert seg[n_segs, 0] == n and run[n_runs, 0] == n_segs                  # terminators
+                assert np.all(np.diff(seg[: n_segs + 1, 0]) >= 0) and np.all(np.diff(run[:, 0]) > 0)
+                starts = set(run[:n_runs, 0].tolist())
+                for g in range(n_segs):
+                    wb, hub, n0, typ = (int(x) for x in seg[g])
+                    we = int(seg[g + 1, 0])
+                    rows = desc[wb:we]
+                    assert np.all(rows[:n0, 2] == none) and np.all(rows[n0:, 2] != none)  # rows without a row to stage lead the segment
+                    assert 0 <= len(rows) - n0 <= 4                                       # <= 4 children with one (rank masks of the exact kernel)
+                    assert n0 <= 8                                                        # (all parentless members share the hub "none": no serial tail)
+                    assert (typ == 0) == (g in starts)
+                    if typ == 0:
+                        assert run[sorted(starts).index(g), 1] == hub
+                    if typ == 1:                                                         # the hub is the row staged last by the previous segment
+                        assert desc[wb - 1, 2] == hub and wb > 0 and seg[g - 1, 0] < wb
+                    if typ == 2:
+                        assert seg[g - 1, 1] == hub and n0 == 0
+                    if typ != 0 and g + 1 < n_segs and len(rows) == n0:
+                        assert (g + 1) in starts                                         # a segment that stages nothing ends its run
+                staged_walk += n_runs + int(np.count_nonzero(desc[:, 2] != none))
+                if max_run is None:
+                    assert not np.any(seg[:n_segs, 3] == 1)                              # no chain steps
+            pl.close()
+            if max_run == "32":
+                full = staged_walk
+            if max_run is None:
+                assert full < 0.9 * staged_walk                                          # chaining stages fewer rows than one run per hub
+    monkeypatch.delenv("GENPHI_FULL_MAX_FLOATS", raising=False)
+    monkeypatch.delenv("GENPHI_MAX_RUN", raising=False)
