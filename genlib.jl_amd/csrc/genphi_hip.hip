@@ -214,6 +214,11 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         double *S = reinterpret_cast<double *>(lds);
         const float4 *a4 = reinterpret_cast<const float4 *>(r.rowA), *b4 = reinterpret_cast<const float4 *>(r.rowB);
         double2 *S2 = reinterpret_cast<double2 *>(S);
+        // the index words of a batch of columns are loaded one batch ahead -- the first batch here, in front of the row loads, so
+        // that it overlaps the staging: a workgroup is alive for ~10 us, and every L2 round trip it waits for alone is ~10 % of that
+        unsigned pkn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pkn[u] = p.pk[min(tid + u * nt, p.n - 1)];
         for (int base = tid; base < nvec; base += 2 * nt) {           // all loads of a batch in flight before the first LDS write
             const int k0 = base, k1 = min(base + nt, nvec - 1);
             const float4 x0 = a4[k0], x1 = a4[k1];
@@ -224,13 +229,17 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
             S2[2 * k1] = make_double2(static_cast<double>(x1.x) + static_cast<double>(y1.x), static_cast<double>(x1.y) + static_cast<double>(y1.y));
             S2[2 * k1 + 1] = make_double2(static_cast<double>(x1.z) + static_cast<double>(y1.z), static_cast<double>(x1.w) + static_cast<double>(y1.w));
         }
-        __syncthreads();
         const double sc = r.new_i ? 0.25 : 0.5;    // row weight times the column's 1/2 (a dragged column is A = B = itself)
         unsigned ckf = 0xffffffffu;
+        __syncthreads();
         for (int j0 = tid; j0 < p.n; j0 += U * nt) {
             unsigned pk[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) pk[u] = p.pk[min(j0 + u * nt, p.n - 1)];
+            for (int u = 0; u < U; ++u) pk[u] = pkn[u];
+            if (j0 + U * nt < p.n) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) pkn[u] = p.pk[min(j0 + U * nt + u * nt, p.n - 1)];
+            }
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) v[u] = static_cast<float>((S[pk[u] & 0xffff] + S[pk[u] >> 16]) * sc);
@@ -1534,7 +1543,7 @@ constexpr size_t kIdxPad = 32 * 1024;
 struct Tuning {
     int lds_cap_floats = 0;        // GENPHI_LDS_CAP_FLOATS   test: LDS budget for staged rows (forces SPLIT / WIDE on small inputs)
     int full_max_floats = -1;      // GENPHI_FULL_MAX_FLOATS  tuning: FULL vs SPLIT threshold (row length in floats)
-    int max_group = 4;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 4)
+    int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
                                    //                         larger: the walk chains from hub to hub (16-20 % fewer staged rows, measured no faster:
                                    //                         profiles/microbench/out/r03_ab_hub_walk_*.out)
@@ -1564,7 +1573,7 @@ static Tuning tuning_from_env()
     auto has = [](const char *name) { return std::getenv(name) != nullptr; };
     t.lds_cap_floats = geti("GENPHI_LDS_CAP_FLOATS", 0);
     t.full_max_floats = geti("GENPHI_FULL_MAX_FLOATS", -1);
-    t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 4));
+    t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
     t.no_identity = has("GENPHI_NO_IDENTITY");
@@ -1618,10 +1627,11 @@ struct DeviceStep {
 
 static void build_groups(const LevelStep &s, const int *rows, const int *out_rows, int n_rows, GroupLists &gl, const Tuning &tun)
 {
-    // segments are capped (<= 4 children: the grouping-exact kernel's rank masks) and so are runs: a workgroup
-    // walks a run's stages one after the other, so one huge run would be a serial tail
+    // segments are capped -- the grouping-exact kernel keeps one 32-bit rank mask per child in 4 VGPRs, so <= 4 children where it
+    // needs them (cut not in rank order), <= 8 where the position test replaces them -- and so are runs: a workgroup walks a
+    // run's stages one after the other, so one huge run would be a serial tail
     genphi::build_hub_walk(s.srcA.data(), s.srcB.data(), s.ord.data(), static_cast<int32_t>(s.n_prev), rows, out_rows, n_rows,
-                           std::min(tun.max_group, 4), tun.max_run, gl.w);
+                           std::min(tun.max_group, s.pos_ord ? 8 : 4), tun.max_run, gl.w);
 }
 
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
@@ -1756,14 +1766,17 @@ extern "C" {
 const char *genphi_last_error(void) { return g_last_error.c_str(); }
 const char *genphi_version(void) { return "genphi-mi355x 0.1 (gfx950)"; }
 
-int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
-                       int64_t n_pro, const int64_t *pro_ids, genphi_plan **out)
+// indices_only: cuts and per-member sources / rank words only (no pk words, work orders or walk lists): all a
+// Float64-storage sweep needs (genphi_phi_pairs builds such a plan per call)
+static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                            int64_t n_pro, const int64_t *pro_ids, bool indices_only, genphi_plan **out)
 {
     if (!out) return fail(GENPHI_ERR_ARG, "genphi_plan_create: out is NULL");
     *out = nullptr;
     genphi_plan *p = new (std::nothrow) genphi_plan();
     if (!p) return fail(GENPHI_ERR_ALLOC, "out of memory");
     p->tun = tuning_from_env();
+    p->popt.indices_only = indices_only;
     if (p->tun.lds_cap_floats >= 16) p->popt.lds_cap_floats = p->tun.lds_cap_floats;
     if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
     std::string err;
@@ -1777,6 +1790,12 @@ int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
     if (rc != GENPHI_OK) { delete p; return fail(rc, err); }
     *out = p;
     return GENPHI_OK;
+}
+
+int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                       int64_t n_pro, const int64_t *pro_ids, genphi_plan **out)
+{
+    return plan_create_impl(n_ind, ind, father, mother, n_pro, pro_ids, false, out);
 }
 
 int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels, const int64_t **cut_sizes,
@@ -2616,6 +2635,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         p->res_ld = pl.ld[L - 1];
         return compute_f64(p, r0, r1, kernel);
     }
+    if (p->popt.indices_only) return fail(GENPHI_ERR_ARG, "internal: an indices-only plan serves Float64-storage sweeps only");
     rc = ensure_level_buffers(p);
     if (rc) return rc;
     const int n_steps = L - 1;
@@ -3131,7 +3151,7 @@ int genphi_phi_pairs(int64_t n_ind, const int64_t *ind, const int64_t *father, c
     ids.reserve(static_cast<size_t>(2 * n_pairs));
     for (int64_t k = 0; k < n_pairs; ++k) { ids.push_back(id_i[k]); ids.push_back(id_j[k]); }
     genphi_plan *pl = nullptr;
-    int rc = genphi_plan_create(n_ind, ind, father, mother, static_cast<int64_t>(ids.size()), ids.data(), &pl);
+    int rc = plan_create_impl(n_ind, ind, father, mother, static_cast<int64_t>(ids.size()), ids.data(), /*indices_only=*/true, &pl);
     if (rc) return rc;
     // position of every named individual in the plan's proband order (duplicates collapsed in first-occurrence order)
     std::vector<int64_t> uniq;

@@ -216,6 +216,7 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
         out.row_k.push_back(k);
     };
     std::vector<int32_t> singles, edges, spill;                 // spill: (hub, row) pairs of rows without B source beyond kMaxSingles per hub visit
+    constexpr size_t kMaxHubChildren = 8;
     constexpr size_t kMaxSingles = 8;                           // a workgroup finishes them one after the other: all parentless members of a cut
                                                                 // share the hub "none", and hundreds of them in one run would be a serial tail
     for (int k0 = 0; k0 < n_rows; ++k0) {
@@ -240,15 +241,20 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
                 const int32_t o = other(edges[e]);
                 if (o != hub && has_work(o)) { next_hub = o; std::swap(edges[e], edges.back()); break; }
             }
-            size_t e = 0;
+            size_t e = 0, in_run = 0;
             bool first = true;
             do {                                                // segments of this hub: its rows without B source lead the first one
                 const size_t m = std::min(edges.size() - e, static_cast<size_t>(seg_cap));
+                int seg_type = first ? type : 2;
+                if (!first && in_run + m > kMaxHubChildren) {   // a hub with many children: a new run (the hub row staged again) every
+                    out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);    // kMaxHubChildren of them, so that
+                    seg_type = 0; in_run = 0;                   // items stay short (tail of the work queue; the chunks of a run stay in step)
+                }
                 out.seg4.push_back(static_cast<int32_t>(out.desc4.size() / 4)); out.seg4.push_back(hub);
-                out.seg4.push_back(first ? static_cast<int32_t>(singles.size()) : 0); out.seg4.push_back(first ? type : 2);
+                out.seg4.push_back(first ? static_cast<int32_t>(singles.size()) : 0); out.seg4.push_back(seg_type);
                 if (first) for (int32_t k : singles) put_row(k, none);
                 for (size_t q = 0; q < m; ++q) put_row(edges[e + q], other(edges[e + q]));
-                e += m;
+                e += m; in_run += m;
                 first = false;
             } while (e < edges.size());
             stages += static_cast<int>(edges.size());

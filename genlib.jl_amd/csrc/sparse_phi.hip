@@ -73,10 +73,19 @@ struct StaleOut {            // entries that outlive their column: (row rank, co
     float *val;
 };
 
-__device__ __forceinline__ void stale_append(const StaleOut &so, int row_rank, int col_rank, float v)
+__device__ __forceinline__ void stale_append(int *cnt, int cap, int2 *rc, float *val, int row_rank, int col_rank, float v)
 {
-    const int k = atomicAdd(so.cnt, 1);
-    if (k < so.cap) { so.rc[k] = make_int2(row_rank, col_rank); so.val[k] = v; }
+    const int k = atomicAdd(cnt, 1);
+    if (k < cap) { rc[k] = make_int2(row_rank, col_rank); val[k] = v; }
+}
+
+// T[i][q] of one new row i and one old slot q (see sparse_rows_kernel); L(parent, q): the self entry of the parent is always
+// found, any other only under the key rule
+__device__ __forceinline__ float rows_entry(int q, int n_old, int2 mq, float a, float b, bool hasF, bool hasM, int fx, int mx, int2 mf, int2 mm)
+{
+    const float lf = (hasF && (q == fx || key_found(mf, mq))) ? a : 0.f;
+    const float lm = (hasM && (q == mx || key_found(mm, mq))) ? b : 0.f;
+    return q < n_old ? static_cast<float>(0.0 + static_cast<double>(half32(lf)) + static_cast<double>(half32(lm))) : 0.f;
 }
 
 // New rows against the old members.  par[i] = (father slot, mother slot, 2 rank + pro of the father, of the
@@ -85,44 +94,49 @@ __device__ __forceinline__ void stale_append(const StaleOut &so, int row_rank, i
 //   next[n_surv + i][newpos[q]] = the same, where q survives
 // Four consecutive old slots per thread: 16-byte loads of the parent rows and of the index words.  Rows of M
 // and T are padded to a multiple of 64 floats and every index array to 256 bytes, so the quads need no clamp.
+// kRowsPerBlock new rows per workgroup share the index words of the thread's four slots (meta: 32 bytes, newpos: 16 bytes --
+// more than the 32 bytes of matrix data one row needs there).
+constexpr int kRowsPerBlock = 4;
 __global__ void __launch_bounds__(256)
 sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
-                   const int2 *__restrict__ meta_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
-                   float *__restrict__ next, long long ld_next, int n_surv, StaleOut so)
+                   const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
+                   float *__restrict__ next, long long ld_next, int n_surv, int *__restrict__ so_cnt, int so_cap, int2 *__restrict__ so_rc,
+                   float *__restrict__ so_val)
 {
-    const int i = blockIdx.x;
-    const int4 p = par[i];
-    const bool hasF = p.x != n_old, hasM = p.y != n_old;             // workgroup-uniform
-    const int2 mf = hasF ? meta[p.x] : make_int2(0, 0), mm = hasM ? meta[p.y] : make_int2(0, 0);
-    const int2 mi = meta_new[i];
-    float *trow = T + (long long)i * ldT;
-    float *orow = next + (long long)(n_surv + i) * ld_next;
     const int q0 = (blockIdx.y * 256 + threadIdx.x) * 4;
     if (q0 >= n_old) return;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 a4 = hasF ? *reinterpret_cast<const float4 *>(M + (long long)p.x * ld + q0) : z4;
-    const float4 b4 = hasM ? *reinterpret_cast<const float4 *>(M + (long long)p.y * ld + q0) : z4;
     const int4 m01 = *reinterpret_cast<const int4 *>(meta + q0), m23 = *reinterpret_cast<const int4 *>(meta + q0 + 2);
     const int4 np4 = *reinterpret_cast<const int4 *>(newpos + q0);
-    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-    const int2 mq[4] = {make_int2(m01.x, m01.y), make_int2(m01.z, m01.w), make_int2(m23.x, m23.y), make_int2(m23.z, m23.w)};
-    const int np[4] = {np4.x, np4.y, np4.z, np4.w};
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = q0 + u;
-        // L(parent, q): the self entry of the parent is always found, any other only under the key rule
-        const float lf = (hasF && (q == p.x || key_found(mf, mq[u]))) ? a[u] : 0.f;
-        const float lm = (hasM && (q == p.y || key_found(mm, mq[u]))) ? b[u] : 0.f;
-        v[u] = q < n_old ? static_cast<float>(0.0 + static_cast<double>(half32(lf)) + static_cast<double>(half32(lm))) : 0.f;
-    }
-    *reinterpret_cast<float4 *>(trow + q0) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {                                    // (no early exit: the arrays must stay in registers)
-        const bool live = q0 + u < n_old;
-        if (live && np[u] >= 0) orow[np[u]] = v[u];
-        // phi[rank_q][rank_i] outlives i's retirement when q is a proband with the larger rank (i a non-proband)
-        if (live && v[u] > 0.f && !(mi.x & 1) && (mq[u].x & 1) && mq[u].x > mi.x) stale_append(so, mq[u].x >> 1, mi.x >> 1, v[u]);
+#pragma unroll 1
+    for (int rr = 0; rr < kRowsPerBlock; ++rr) {
+        const int i = blockIdx.x * kRowsPerBlock + rr;
+        if (i >= n_new) break;                                       // (workgroup-uniform)
+        const int4 p = par[i];
+        const bool hasF = p.x != n_old, hasM = p.y != n_old;         // workgroup-uniform
+        const int2 mf = hasF ? meta[p.x] : make_int2(0, 0), mm = hasM ? meta[p.y] : make_int2(0, 0);
+        const int2 mi = meta_new[i];
+        float *trow = T + (long long)i * ldT;
+        float *orow = next + (long long)(n_surv + i) * ld_next;
+        // (unconditional loads from a valid row: a select between a global pointer and a zero constant becomes a FLAT load of a
+        // private copy; rows_entry drops the values of a missing parent)
+        const float4 a4 = *reinterpret_cast<const float4 *>(M + (long long)(hasF ? p.x : 0) * ld + q0);
+        const float4 b4 = *reinterpret_cast<const float4 *>(M + (long long)(hasM ? p.y : 0) * ld + q0);
+        const float v0 = rows_entry(q0, n_old, make_int2(m01.x, m01.y), a4.x, b4.x, hasF, hasM, p.x, p.y, mf, mm);
+        const float v1 = rows_entry(q0 + 1, n_old, make_int2(m01.z, m01.w), a4.y, b4.y, hasF, hasM, p.x, p.y, mf, mm);
+        const float v2 = rows_entry(q0 + 2, n_old, make_int2(m23.x, m23.y), a4.z, b4.z, hasF, hasM, p.x, p.y, mf, mm);
+        const float v3 = rows_entry(q0 + 3, n_old, make_int2(m23.z, m23.w), a4.w, b4.w, hasF, hasM, p.x, p.y, mf, mm);
+        *reinterpret_cast<float4 *>(trow + q0) = make_float4(v0, v1, v2, v3);
+        // next[new row][survivor column]; phi[rank_q][rank_i] outlives i's retirement when q is a proband with the larger rank (i a non-proband)
+#define GENPHI_SPARSE_EMIT(U, V, MQX, NP)                                                                                         \
+        if (q0 + U < n_old) {                                                                                                     \
+            if (NP >= 0) orow[NP] = V;                                                                                            \
+            if (V > 0.f && !(mi.x & 1) && (MQX & 1) && MQX > mi.x) stale_append(so_cnt, so_cap, so_rc, so_val, MQX >> 1, mi.x >> 1, V); \
+        }
+        GENPHI_SPARSE_EMIT(0, v0, m01.x, np4.x)
+        GENPHI_SPARSE_EMIT(1, v1, m01.z, np4.y)
+        GENPHI_SPARSE_EMIT(2, v2, m23.x, np4.z)
+        GENPHI_SPARSE_EMIT(3, v3, m23.z, np4.w)
+#undef GENPHI_SPARSE_EMIT
     }
 }
 
@@ -194,7 +208,7 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
             orow[b] = v;
             if (v > 0.f && (ma.x & 1)) {
                 const int2 mb = meta_new[b];                      // b is the later one: phi[rank_a][rank_b] outlives b's retirement
-                if (!(mb.x & 1) && ma.x > mb.x) stale_append(so, ma.x >> 1, mb.x >> 1, v);      // if a is a proband with the larger rank
+                if (!(mb.x & 1) && ma.x > mb.x) stale_append(so.cnt, so.cap, so.rc, so.val, ma.x >> 1, mb.x >> 1, v);      // if a is a proband with the larger rank
             }
         }
     }
@@ -441,9 +455,9 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             const int *d_keep = reinterpret_cast<const int *>(d_blob + w.o_keep), *d_newpos = reinterpret_cast<const int *>(d_blob + w.o_newpos);
             const int2 *d_meta_new = reinterpret_cast<const int2 *>(d_blob + w.o_meta_new), *d_meta_old = reinterpret_cast<const int2 *>(d_blob + w.o_meta_old);
             if (w.n_new > 0 && w.n_old > 0) {
-                dim3 grid(static_cast<unsigned>(w.n_new), static_cast<unsigned>((w.n_old + 1023) / 1024));
-                hipLaunchKernelGGL(sparse_rows_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new,
-                                   d_newpos, dT, ldT, dM[cur ^ 1], ld_next, w.n_surv, so);
+                dim3 grid(static_cast<unsigned>((w.n_new + kRowsPerBlock - 1) / kRowsPerBlock), static_cast<unsigned>((w.n_old + 1023) / 1024));
+                hipLaunchKernelGGL(sparse_rows_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new, w.n_new,
+                                   d_newpos, dT, ldT, dM[cur ^ 1], ld_next, w.n_surv, so.cnt, so.cap, so.rc, so.val);
                 SP_GO(hipGetLastError());
             }
             if (w.n_surv > 0) {

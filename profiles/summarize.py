@@ -9,6 +9,7 @@ coalesced read stream -- the staging loads of the level kernels are that -- so i
 WRITE_SIZE is taken as is (it matches the known output bytes of these kernels to <1 %)."""
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -52,13 +53,18 @@ def agg(path):
 
 
 F, W = agg(one("pmc_fetch/*/*counter_collection.csv")), agg(one("pmc_write/*/*counter_collection.csv"))
+try:
+    T = agg(one("pmc_tcp/*/*counter_collection.csv"))      # requests from the CUs into L2 (64-byte requests)
+except Exception:
+    T = {}
 KERNELS = ("level_", "levels_small", "rows_compact", "transpose_block", "copy_block", "pad_zero", "colperm", "group_split")
 rows, tot, sweeps, steps = [], 0.0, 0, 0
 for k in F:
     name = F[k]["name"]
     if not any(t in name for t in KERNELS) or k not in W:
         continue
-    short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+    m = re.search(r"\(anonymous namespace\)::([A-Za-z_0-9]+(?:<[^>]*>)?)\(", name)      # (the argument list names the namespace again)
+    short = (m.group(1) if m else name.split("(")[0]).replace(", ", ",")
     if "level_identity_kernel" in name:
         sweeps += 1                                        # one per gen.phi sweep (level step 0)
     if F[k]["ms"] < 0.02 and "level_split_kernel" in name:
@@ -66,12 +72,13 @@ for k in F:
     rd = F[k].get("FETCH_SIZE", 0.0) * 1024 * 2            # KiB -> B, gfx950 wide-read correction
     wr = W[k].get("WRITE_SIZE", 0.0) * 1024
     hit, miss = W[k].get("TCC_HIT_sum", 0.0), W[k].get("TCC_MISS_sum", 0.0)
-    rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1)))
+    rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1),
+                 int(T.get(k, {}).get("TCP_TCC_READ_REQ_sum", -1)), int(T.get(k, {}).get("TCP_TCC_WRITE_REQ_sum", -1))))
     tot += rd + wr
 with open(os.path.join(dst, f"{tag}_{wl}_levels.csv"), "w") as fh:
-    fh.write("dispatch,kernel,ms_under_pmc,hbm_read_bytes,hbm_write_bytes,l2_hit_pct\n")
+    fh.write("dispatch,kernel,ms_under_pmc,hbm_read_bytes,hbm_write_bytes,l2_hit_pct,tcp_tcc_read_req,tcp_tcc_write_req\n")
     for r in rows:
-        fh.write(",".join(str(x) for x in r) + "\n")
+        fh.write(",".join(('"%s"' % x) if isinstance(x, str) else str(x) for x in r) + "\n")
 # level steps per sweep: from the bench line of the kernel-trace run
 n_steps = None
 try:

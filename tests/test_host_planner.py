@@ -285,11 +285,13 @@ def test_hub_walk_work_lists(monkeypatch):
                     we = int(seg[g + 1, 0])
                     rows = desc[wb:we]
                     assert np.all(rows[:n0, 2] == none) and np.all(rows[n0:, 2] != none)  # rows without a row to stage lead the segment
-                    assert 0 <= len(rows) - n0 <= 4                                       # <= 4 children with one (rank masks of the exact kernel)
+                    assert 0 <= len(rows) - n0 <= 8                                       # <= 8 children with one (<= 4 where the exact kernel keeps rank masks)
                     assert n0 <= 8                                                        # (all parentless members share the hub "none": no serial tail)
                     assert (typ == 0) == (g in starts)
                     if typ == 0:
                         assert run[sorted(starts).index(g), 1] == hub
+                        if g + 1 < n_segs and seg[g + 1, 3] == 2:                         # a hub's children beyond 8: a new run
+                            assert seg[g + 1, 1] == hub
                     if typ == 1:                                                         # the hub is the row staged last by the previous segment
                         assert desc[wb - 1, 2] == hub and wb > 0 and seg[g - 1, 0] < wb
                     if typ == 2:
