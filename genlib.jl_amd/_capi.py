@@ -281,12 +281,12 @@ class PhiPlan:
 
     def step_walk(self, step):
         """Work lists of SPLIT level step `step` (the hub walk, csrc/planner.h): (desc, seg, run) as int32 arrays of
-        shape (rows, 4), (segments, 4), (runs, 2), terminators dropped."""
+        shape (rows, 4), (segments + 2, 4), (runs + 1, 4) (terminators included; run = first segment, hub | n0 << 16, its rows)."""
         nr, ns, nu = C.c_int64(), C.c_int64(), C.c_int64()
         rc = lib().genphi_plan_step_walk(self._h, int(step), C.byref(nr), C.byref(ns), C.byref(nu), None, None, None)
         if rc:
             _raise(rc)
-        desc = np.zeros((nr.value, 4), np.int32); seg = np.zeros((ns.value + 2, 4), np.int32); run = np.zeros((nu.value + 1, 2), np.int32)
+        desc = np.zeros((nr.value, 4), np.int32); seg = np.zeros((ns.value + 2, 4), np.int32); run = np.zeros((nu.value + 1, 4), np.int32)
         i32 = C.POINTER(C.c_int32)
         rc = lib().genphi_plan_step_walk(self._h, int(step), None, None, None, desc.ctypes.data_as(i32), seg.ctypes.data_as(i32), run.ctypes.data_as(i32))
         if rc:

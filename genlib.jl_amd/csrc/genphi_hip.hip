@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         // that it overlaps the staging: a workgroup is alive for ~10 us, and every L2 round trip it waits for alone is ~10 % of that
         unsigned pkn[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pkn[u] = p.pk[min(tid + u * nt, p.n - 1)];
+        for (int u = 0; u < U; ++u) pkn[u] = p.pk[max(min(tid + u * nt, p.n - 1), 0)];      // (a rank's panel may have no column at all: n = 0)
         for (int base = tid; base < nvec; base += 2 * nt) {           // all loads of a batch in flight before the first LDS write
             const int k0 = base, k1 = min(base + nt, nvec - 1);
             const float4 x0 = a4[k0], x1 = a4[k1];
@@ -682,7 +682,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 
 // Bit-identical to the grouping-exact kernel on certified rows (tests force both on the same input).
 template <int NTHREADS, int CPT, int STG, bool CERT>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int2 *__restrict__ run,
+level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int4 *__restrict__ run,
                         const int *__restrict__ glist, int *queue)
 {
     extern __shared__ float lds[];
@@ -736,9 +736,9 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         const int chunk = cur_l - rk * p.n_chunks;
         // (glist is a kernel argument of its own, const and restrict: its loads are scalar.  Read through the
         // argument struct they were vector loads, and waiting for one drains vmcnt -- row stores included)
-        const int r = glist[rk];
-        g = run[r].x; g_end = run[r + 1].x;
-        wb = seg[g].x; we = seg[g + 1].x; n0 = seg[g].z; Ai = seg[g].y;
+        const int4 rr = run[glist[rk]];                   // (first segment, hub | n0 << 16, its rows [z, w))
+        g = rr.x; g_end = run[glist[rk] + 1].x;
+        wb = rr.z; we = rr.w; n0 = rr.y >> 16; Ai = rr.y & 0xffff;
         cb = (unsigned)chunk * (unsigned)p.chunk_cols;
         ce = min(cb + (unsigned)p.chunk_cols, (unsigned)p.width);
     }
@@ -786,7 +786,9 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         // the next item's run (a dummy one when nothing is left: an unconditional prefetch keeps `pre` in one set)
         const int rkn = have_next ? (p.chunk_magic ? static_cast<int>(__umulhi(static_cast<unsigned>(nxt_l), p.chunk_magic)) : nxt_l) : 0;
         const int rn = glist[rkn];
-        const int gn = run[rn].x, nextAi = run[rn].y;     // its first segment and that segment's hub row
+        const int4 nrun = run[rn];                        // its first segment: (index, hub row | n0 << 16, rows [z, w)); ONE load chain per
+        const int gn_end = run[rn + 1].x;                 // item, issued a stage ahead: nothing is loaded when the item starts
+        const int nextAi = nrun.y & 0xffff;
         // index loads and the queue draw BEFORE the prefetch (vmcnt retires in order); the prefetch itself
         // is issued piece by piece as the LDS writes free the staging registers, so it leads by the LDS
         // writes and the second barrier
@@ -898,8 +900,8 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         } else {                                        // next stage: the first segment of the next item
             if (!have_next) break;
             const int chunk = nxt_l - rkn * p.n_chunks;
-            g = gn; g_end = run[rn + 1].x;
-            wb = seg[g].x; we = seg[g + 1].x; n0 = seg[g].z; Ai = nextAi;
+            g = nrun.x; g_end = gn_end;
+            wb = nrun.z; we = nrun.w; n0 = nrun.y >> 16; Ai = nextAi;
             w = wb;
             stage_is_a = true;
             cb = (unsigned)chunk * (unsigned)p.chunk_cols;
@@ -918,7 +920,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
 // costs two dependent loads per row at memory latency: 64 us per level where this takes 5), 32 runs per block.
 constexpr int kSplitLanes = 8, kSplitRuns = 256 / kSplitLanes;
 __global__ void __launch_bounds__(256)
-group_split_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int2 *__restrict__ run, int n_runs,
+group_split_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int4 *__restrict__ run, int n_runs,
                    const int *__restrict__ cert_prev, int *__restrict__ list0, int *__restrict__ list1, int *__restrict__ cnt)
 {
     __shared__ int good[kSplitRuns];
@@ -930,7 +932,7 @@ group_split_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ seg, 
     if (live) {
         g0 = run[r].x; g1 = run[r + 1].x;
         const int wb = seg[g0].x, we = seg[g1].x;
-        if (sub == 0) bad = cert_prev[run[r].y];          // "none" (index n_prev) is never flagged
+        if (sub == 0) bad = cert_prev[run[r].y & 0xffff];  // "none" (index n_prev) is never flagged
         for (int w = wb + sub; w < we; w += kSplitLanes) bad |= cert_prev[desc[w].z];
     }
 #pragma unroll
@@ -1609,7 +1611,7 @@ struct GroupLists {
 };
 struct DeviceGroups {
     int4 *desc = nullptr, *seg = nullptr;
-    int2 *run = nullptr;       // (first segment, hub row of it) per run + terminator
+    int4 *run = nullptr;       // (first segment, hub row | n0 << 16, its rows [z, w)) per run + terminator
     int n_segs = 0, n_runs = 0;
 };
 
@@ -1645,9 +1647,9 @@ static void put_groups(const GroupLists &gl, DeviceGroups &d, Put &&put)
 {
     d.desc = reinterpret_cast<int4 *>(put(gl.w.desc4.data(), gl.w.desc4.size() * sizeof(int)));
     d.seg = reinterpret_cast<int4 *>(put(gl.w.seg4.data(), gl.w.seg4.size() * sizeof(int)));
-    d.run = reinterpret_cast<int2 *>(put(gl.w.run.data(), gl.w.run.size() * sizeof(int)));
+    d.run = reinterpret_cast<int4 *>(put(gl.w.run.data(), gl.w.run.size() * sizeof(int)));
     d.n_segs = static_cast<int>(gl.w.seg4.size() / 4) - 2;
-    d.n_runs = static_cast<int>(gl.w.run.size() / 2) - 1;
+    d.n_runs = static_cast<int>(gl.w.run.size() / 4) - 1;
 }
 
 struct genphi_plan {
@@ -1826,7 +1828,7 @@ int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info)
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
 
 int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows, int64_t *n_segs, int64_t *n_runs, int32_t *desc4,
-                          int32_t *seg4, int32_t *run2)
+                          int32_t *seg4, int32_t *run4)
 {
     if (!plan || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size()))
         return fail(GENPHI_ERR_ARG, "genphi_plan_step_walk: bad argument");
@@ -1836,10 +1838,10 @@ int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows
     build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), gl, plan->tun);
     if (n_rows) *n_rows = static_cast<int64_t>(gl.w.desc4.size() / 4);
     if (n_segs) *n_segs = static_cast<int64_t>(gl.w.seg4.size() / 4) - 2;
-    if (n_runs) *n_runs = static_cast<int64_t>(gl.w.run.size() / 2) - 1;
+    if (n_runs) *n_runs = static_cast<int64_t>(gl.w.run.size() / 4) - 1;
     if (desc4) std::memcpy(desc4, gl.w.desc4.data(), gl.w.desc4.size() * sizeof(int32_t));
     if (seg4) std::memcpy(seg4, gl.w.seg4.data(), gl.w.seg4.size() * sizeof(int32_t));
-    if (run2) std::memcpy(run2, gl.w.run.data(), gl.w.run.size() * sizeof(int32_t));
+    if (run4) std::memcpy(run4, gl.w.run.data(), gl.w.run.size() * sizeof(int32_t));
     return GENPHI_OK;
 }
 
@@ -2133,7 +2135,7 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
 // holds ~25 % more columns -- 4 column chunks instead of 5 for the 1e5-wide final level of cfg4)
 template <int NT, int C, int S, bool CERT>
 static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
-                                   const int4 *grp, const int2 *run, int *queue)
+                                   const int4 *grp, const int4 *run, int *queue)
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
     if (e != hipSuccess) return e;
@@ -2151,7 +2153,7 @@ static int fast_max_cpt(int nt, int stg)
 
 template <bool CERT>
 static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
-                              const int4 *desc, const int4 *grp, const int2 *run, int *queue)
+                              const int4 *desc, const int4 *grp, const int4 *run, int *queue)
 {
 #define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT>(grid, lds, stream, a, desc, grp, run, queue)
 #ifdef GENPHI_MIN_INST
@@ -2405,7 +2407,7 @@ int genphi::launch_panel_level(const PanelLaunch &L)
     R.queue = L.counters; R.gcnt = L.counters + 16;
     R.glist_f = L.glist; R.glist_s = L.glist + L.glist_cap;
     DeviceGroups dg;
-    dg.desc = const_cast<int4 *>(L.desc); dg.seg = const_cast<int4 *>(L.seg); dg.run = const_cast<int2 *>(L.run);
+    dg.desc = const_cast<int4 *>(L.desc); dg.seg = const_cast<int4 *>(L.seg); dg.run = const_cast<int4 *>(L.run);
     dg.n_segs = L.n_segs; dg.n_runs = L.n_runs;
     return launch_rows(R, a, L.mode, /*pos_ord=*/false, L.src_width, L.ld, /*kernel=*/0, dg);
 }

@@ -31,7 +31,7 @@ struct PanelLaunch {
     int mode;                    // 0 FULL, 1 SPLIT
     const int4 *desc;            // SPLIT: the hub walk of the cut's rows (WalkLists, planner.h): per work row (row, row, B source, rank word)
     const int4 *seg;             // SPLIT: per segment (first work row, hub row, leading rows without B source, type) + terminators
-    const int2 *run;             // SPLIT: (first segment, its hub row) of every run + terminator
+    const int4 *run;             // SPLIT: (first segment, hub row | n0 << 16, its rows [z, w)) of every run + terminator
     const int2 *pdesc;           // SPLIT: per work row (local column or -1, panel column of the member's OTHER source: the hub of its segment)
     int n_segs, n_runs;
     const int *cert_prev;        // exactness certificates of the rows of psi (this rank's columns of them)

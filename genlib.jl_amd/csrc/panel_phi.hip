@@ -168,7 +168,8 @@ struct DevPanelStep {
     unsigned *pk_col = nullptr;
     int *ord_col = nullptr, *diag_col = nullptr, *work = nullptr;
     int4 *desc = nullptr, *seg = nullptr;
-    int2 *run = nullptr, *pdesc = nullptr;
+    int4 *run = nullptr;
+    int2 *pdesc = nullptr;
 };
 
 }  // namespace
@@ -366,7 +367,7 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
                 // self kinship 1/2 + Psi[B][hub]/2 is read from it)
                 genphi::build_hub_walk(st.srcA.data(), st.srcB.data(), st.ord.data(), n_prev, ps.work.data(), nullptr, static_cast<int>(st.n), 4, 1, ps.walk);
                 ps.n_segs = static_cast<int>(ps.walk.seg4.size() / 4) - 2;
-                ps.n_runs = static_cast<int>(ps.walk.run.size() / 2) - 1;
+                ps.n_runs = static_cast<int>(ps.walk.run.size() / 4) - 1;
                 ps.pdesc.resize(st.n);
                 for (int g = 0; g < ps.n_segs; ++g) {
                     const int hub = ps.walk.seg4[4 * g + 1];
@@ -463,7 +464,7 @@ static int panel_upload_impl(genphi_panel *p, int device)
         if (!need[b]) continue;
         need[b] += 64 * 1024;                               // zeroed tail: the SPLIT kernels stage whole float4 batches past the last row
         PN_TRY(pmalloc(reinterpret_cast<void **>(&p->panel[b]), need[b] * sizeof(float)));
-        PN_TRY(hipMemset(p->panel[b], 0, need[b] * sizeof(float)));
+        PN_TRY(hipMemsetAsync(p->panel[b], 0, need[b] * sizeof(float), p->stream));   // (on the handle's stream: the null stream is not ordered with it)
         p->panel_floats[b] = need[b];
     }
     auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {

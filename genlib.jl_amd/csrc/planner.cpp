@@ -222,7 +222,7 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
     for (int k0 = 0; k0 < n_rows; ++k0) {
         if (done[k0]) continue;
         int32_t hub = srcA[rows[k0]];
-        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);
+        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub); out.run.push_back(0); out.run.push_back(0);
         int type = 0, stages = 1;                               // (the staged hub row of the run's first segment)
         for (;;) {
             singles.clear(); edges.clear();
@@ -248,6 +248,7 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
                 int seg_type = first ? type : 2;
                 if (!first && in_run + m > kMaxHubChildren) {   // a hub with many children: a new run (the hub row staged again) every
                     out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);    // kMaxHubChildren of them, so that
+                    out.run.push_back(0); out.run.push_back(0);
                     seg_type = 0; in_run = 0;                   // items stay short (tail of the work queue; the chunks of a run stay in step)
                 }
                 out.seg4.push_back(static_cast<int32_t>(out.desc4.size() / 4)); out.seg4.push_back(hub);
@@ -269,14 +270,21 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
         const int32_t hub = spill[q];
         size_t e = q;
         while (e < spill.size() && spill[e] == hub && (e - q) / 2 < kMaxSingles) e += 2;
-        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub);
+        out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(hub); out.run.push_back(0); out.run.push_back(0);
         out.seg4.push_back(static_cast<int32_t>(out.desc4.size() / 4)); out.seg4.push_back(hub);
         out.seg4.push_back(static_cast<int32_t>((e - q) / 2)); out.seg4.push_back(0);
         for (; q < e; q += 2) put_row(spill[q + 1], none);
     }
-    out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(0);
+    out.run.push_back(static_cast<int32_t>(out.seg4.size() / 4)); out.run.push_back(0); out.run.push_back(n_rows); out.run.push_back(n_rows);
     out.seg4.push_back(n_rows); out.seg4.push_back(0); out.seg4.push_back(0); out.seg4.push_back(0);       // terminator (two, so that seg[g + 2] is readable)
     out.seg4.push_back(n_rows); out.seg4.push_back(0); out.seg4.push_back(0); out.seg4.push_back(0);
+    // a run's entry also carries its first segment (one scalar load starts an item): rows [z, w), n0 in the high half of y
+    for (size_t r = 0; r + 1 < out.run.size() / 4; ++r) {
+        const int32_t g = out.run[4 * r];
+        out.run[4 * r + 1] |= out.seg4[4 * g + 2] << 16;
+        out.run[4 * r + 2] = out.seg4[4 * g];
+        out.run[4 * r + 3] = out.seg4[4 * (g + 1)];
+    }
 }
 
 int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,

@@ -113,7 +113,8 @@ void reuse_order(const LevelStep &step, std::vector<int32_t> &rows);
 //   seg4[4 g ..]   = (first work row, hub row, number of leading work rows without B source, type)  + a terminator
 //                    type 0: the run starts here (the hub row is staged), 1: the hub is the B row of the previous
 //                    segment's last child (its expansion is already in registers), 2: same hub as the previous segment
-//   run[2 r ..]    = (first segment of run r, its hub row)  + a terminator
+//   run[4 r ..]    = (first segment of run r, its hub row | its n0 << 16, its first work row, its end work row)  + a terminator
+//                    (the first segment again, so that ONE load starts an item; hub rows are < 65536 in SPLIT steps)
 // Random mating (every member about two children): ~16 % fewer staged rows per level than one group per father;
 // the 1e5-wide last level of cfg4: ~12 % fewer.  The order of the start rows follows `rows` (the planner's reuse order).
 struct WalkLists {

@@ -104,10 +104,11 @@ int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info);
 /* Diagnostic: the work lists of SPLIT level step `step` -- the hub walk over the parent graph of the cut's rows
  * (csrc/planner.h, WalkLists): desc4 = 4 ints per work row (storage row, output row, row to stage or n_prev, rank word),
  * seg4 = 4 ints per segment (first work row, hub row, leading rows without a row to stage, type 0 / 1 / 2) + 2
- * terminators, run2 = 2 ints per run (first segment, hub row) + 1 terminator.  Call with NULL arrays for the counts.
+ * terminators, run4 = 4 ints per run (first segment, hub row | n0 << 16, first and end work row of that segment) + 1
+ * terminator.  Call with NULL arrays for the counts.
  * Tests check its invariants (every row once; a type-1 hub is the row staged last; staged rows <= one per child + one per run). */
 int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows, int64_t *n_segs, int64_t *n_runs,
-                          int32_t *desc4, int32_t *seg4, int32_t *run2);
+                          int32_t *desc4, int32_t *seg4, int32_t *run4);
 
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);

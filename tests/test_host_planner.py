@@ -289,7 +289,8 @@ def test_hub_walk_work_lists(monkeypatch):
                     assert n0 <= 8                                                        # (all parentless members share the hub "none": no serial tail)
                     assert (typ == 0) == (g in starts)
                     if typ == 0:
-                        assert run[sorted(starts).index(g), 1] == hub
+                        rr = run[sorted(starts).index(g)]                                # the run's entry repeats its first segment
+                        assert (rr[1] & 0xffff, rr[1] >> 16, rr[2], rr[3]) == (hub, n0, wb, we)
                         if g + 1 < n_segs and seg[g + 1, 3] == 2:                         # a hub's children beyond 8: a new run
                             assert seg[g + 1, 1] == hub
                     if typ == 1:                                                         # the hub is the row staged last by the previous segment
