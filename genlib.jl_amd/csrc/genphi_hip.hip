@@ -133,7 +133,9 @@ struct LevelArgs {
     // source "row" is a row of the rank's extended panel (own + received columns; pk indexes into it).
     const int *ord_col;      // rank word per column (= ord unless panel)
     const int *diag_col;     // panel: local column of row member i, or -1 (nullptr: column i)
-    const int2 *pdesc;       // panel, SPLIT: per work row (local column of the member or -1, panel column of its A source)
+    const int2 *pdesc;       // panel, SPLIT: per work row (local column of the member or -1, panel column of its other source); handed to the
+                             // kernels as an argument of its own (const, restrict: scalar loads -- through this struct they are vector loads,
+                             // and the wait for one drains vmcnt, i.e. the next row's prefetch, at the start of every stage)
     int zrow;                // index of the all-zero "none" row of `out` (= n unless panel: the cut's size)
 };
 
@@ -382,7 +384,8 @@ __device__ unsigned long long g_wg_phase[2][1024][16];   // [thread 0 | last thr
 
 template <int NTHREADS, int CPT, int STG, bool POS_ORD>
 __global__ void __launch_bounds__(NTHREADS)
-level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int *__restrict__ glist, int *queue)
+level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int *__restrict__ glist,
+                   const int2 *__restrict__ pdesc, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -583,8 +586,8 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 
             float *orowp = p.out + (long long)orow * p.ld;
             const int e_ij = (new_i ? -1 : 0) - 1;       // 2^e: row weight times the column's 1/2
             // diagonal of a new member: 1/2 + Psi[A][B]/2 = 1/2 + Psi[B][A]/2 (bit-symmetric)
-            const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
-            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[p.pdesc ? p.pdesc[w].y : Ai]));
+            const int dcol = pdesc ? pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[pdesc ? pdesc[w].y : Ai]));
             const int qk = w - (wb + n0);               // which child of the segment (wave-uniform)
             const unsigned hi_bits = POS_ORD ? 0u : (qk == 0 ? hb0 : (qk == 1 ? hb1 : (qk == 2 ? hb2 : hb3)));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -624,7 +627,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 
             __builtin_assume(tlf < NT);
             const int4 df = desc[wf];
             const bool new_f = df.w < 0;
-            const unsigned dcol_f = static_cast<unsigned>(p.pdesc ? p.pdesc[wf].x : df.x);     // (-1 matches no column)
+            const unsigned dcol_f = static_cast<unsigned>(pdesc ? pdesc[wf].x : df.x);     // (-1 matches no column)
             float *orowp = p.out + (long long)df.y * p.ld;
             const int e_ij = (new_f ? -1 : 0) - 1;
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -683,7 +686,7 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 
 template <int NTHREADS, int CPT, int STG, bool CERT>
 __global__ void __launch_bounds__(NTHREADS)
 level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int4 *__restrict__ run,
-                        const int *__restrict__ glist, int *queue)
+                        const int *__restrict__ glist, const int2 *__restrict__ pdesc, int *queue)
 {
     extern __shared__ float lds[];
     constexpr unsigned NT = NTHREADS;
@@ -817,8 +820,8 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
         if (!stage_is_a) {
             float *orowp = p.out + (long long)orow * p.ld;
             // a row with a B source is a new member with both parents: weight 1/2 x 1/2 per column
-            const int dcol = p.pdesc ? p.pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
-            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[p.pdesc ? p.pdesc[w].y : Ai]));
+            const int dcol = pdesc ? pdesc[w].x : ri;           // the member's own column (panel: local column or -1)
+            const float diag = static_cast<float>(0.5 + 0.5 * static_cast<double>(sR[pdesc ? pdesc[w].y : Ai]));
             const unsigned row_bytes = (unsigned)p.ld * 4u;
             unsigned ck = 0xffffffffu;
 #pragma unroll
@@ -864,7 +867,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             __builtin_assume(tlf < NT);
             const int4 df = desc[wf];
             const bool new_f = df.w < 0;
-            const unsigned dcol_f = static_cast<unsigned>(p.pdesc ? p.pdesc[wf].x : df.x);     // (-1 matches no column)
+            const unsigned dcol_f = static_cast<unsigned>(pdesc ? pdesc[wf].x : df.x);     // (-1 matches no column)
             float *orowp = p.out + (long long)df.y * p.ld;
             const double sc = new_f ? 1.0 : 2.0;          // pab carries 1/4; a dragged row weighs 1, not 1/2
             const unsigned row_bytes = (unsigned)p.ld * 4u;
@@ -2107,7 +2110,7 @@ static hipError_t launch_split_inst(int grid, size_t lds, hipStream_t stream, co
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_kernel<1024, C, S, O>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_kernel<1024, C, S, O>), dim3(grid), dim3(1024), lds, stream, a, desc, grp, a.glist, queue);
+    hipLaunchKernelGGL((level_split_kernel<1024, C, S, O>), dim3(grid), dim3(1024), lds, stream, a, desc, grp, a.glist, a.pdesc, queue);
     return hipGetLastError();
 }
 
@@ -2139,7 +2142,7 @@ static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, con
 {
     hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, run, a.glist, queue);
+    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, run, a.glist, a.pdesc, queue);
     return hipGetLastError();
 }
 
