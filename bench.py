@@ -56,15 +56,14 @@ def measured_ceiling():
     return None, None
 
 
-def csrc_sha16():
-    """Fingerprint of genlib.jl_amd/csrc (same function as profiles/summarize.py): ties a committed
-    profiles/traffic_<workload>.json to the kernel sources it was collected with."""
+def csrc_sha16(root=None):
+    """Fingerprint of the kernel sources of the DENSE path (what the traffic files measure): ties a committed
+    profiles/traffic_<workload>.json to the sources it was collected with (works on the GPU box, which has no .git)."""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "genlib.jl_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".cpp", ".h")):
-            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    d = os.path.join(root or ROOT, "genlib.jl_amd", "csrc")
+    for name in ("genphi_hip.hip", "planner.cpp", "planner.h", "panel_launch.h"):
+        h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

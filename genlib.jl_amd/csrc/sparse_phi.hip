@@ -175,8 +175,9 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
     extern __shared__ float srow[];
     const int a = blockIdx.x;
     const float *trow = T + (long long)a * ldT;
-    const bool in_lds = lds_floats >= n_old;
-    if (in_lds && a + 1 < n_new) {                                // (uniform: a and n_new are)
+    // (staging the row costs n_old loads: not worth it for the last rows of the wave, which have few later partners)
+    const bool in_lds = lds_floats >= n_old && 8 * (n_new - a - 1) >= n_old;
+    if (in_lds) {                                                 // (uniform: a and n_new are)
         const float4 *g4 = reinterpret_cast<const float4 *>(trow);
         float4 *s4 = reinterpret_cast<float4 *>(srow);
         for (int k = threadIdx.x; k < (n_old + 3) / 4; k += 256) s4[k] = g4[k];       // (T's pitch is a multiple of 64 floats)
@@ -223,9 +224,16 @@ sparse_mirror_kernel(float *__restrict__ next, long long ld, int n_surv, int n_n
     const int r0 = n_surv + blockIdx.y * 64, c0 = blockIdx.x * 64;
     if (c0 >= n_surv && c0 + 63 <= r0) return;                    // a tile on or below the diagonal of new x new with nothing to mirror
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = ty; k < 64; k += 4) {
-        const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < n_next && c < n_next && (c < n_surv || c > r)) ? next[(long long)r * ld + c] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                 // 8 loads in flight per thread (clamped: unconditional loads)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = min(r0 + ty + 4 * (8 * h + u), n_next - 1), c = min(c0 + tx, n_next - 1);
+            v[u] = next[(long long)r * ld + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tile[ty + 4 * (8 * h + u)][tx] = v[u];
     }
     __syncthreads();
     for (int k = ty; k < 64; k += 4) {

@@ -21,19 +21,15 @@ import hashlib
 tag, wl = (sys.argv + ["r01", "cfg4"])[1:3]
 
 
-def csrc_sha16(root):
-    """Fingerprint of the kernel sources the counters were collected with (bench.py recomputes it and
-    says "stale" when the sources have changed since; works on the GPU box, which has no .git)."""
+def csrc_sha16(root=None):
+    """Fingerprint of the kernel sources of the DENSE path (what the traffic files measure): ties a committed
+    profiles/traffic_<workload>.json to the sources it was collected with (works on the GPU box, which has no .git)."""
+    import hashlib
     h = hashlib.sha256()
     d = os.path.join(root, "genlib.jl_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".cpp", ".h")):
-            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    for name in ("genphi_hip.hip", "planner.cpp", "planner.h", "panel_launch.h"):
+        h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
-
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
-dst = os.path.join(root, "profiles")
 
 
 def one(pattern):
