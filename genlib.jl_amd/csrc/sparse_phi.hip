@@ -107,20 +107,29 @@ sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__rest
     if (q0 >= n_old) return;
     const int4 m01 = *reinterpret_cast<const int4 *>(meta + q0), m23 = *reinterpret_cast<const int4 *>(meta + q0 + 2);
     const int4 np4 = *reinterpret_cast<const int4 *>(newpos + q0);
-#pragma unroll 1
+    // all source-row loads of the block's rows are issued before the first use (8 float4 loads in flight per lane)
+    int4 pr[kRowsPerBlock];
+    float4 a4s[kRowsPerBlock], b4s[kRowsPerBlock];
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerBlock; ++rr) {
+        const int i = min(blockIdx.x * kRowsPerBlock + rr, n_new - 1);
+        pr[rr] = par[i];
+        // (unconditional loads from a valid row: a select between a global pointer and a zero constant becomes a FLAT load of a
+        // private copy; rows_entry drops the values of a missing parent)
+        a4s[rr] = *reinterpret_cast<const float4 *>(M + (long long)(pr[rr].x != n_old ? pr[rr].x : 0) * ld + q0);
+        b4s[rr] = *reinterpret_cast<const float4 *>(M + (long long)(pr[rr].y != n_old ? pr[rr].y : 0) * ld + q0);
+    }
+#pragma unroll
     for (int rr = 0; rr < kRowsPerBlock; ++rr) {
         const int i = blockIdx.x * kRowsPerBlock + rr;
         if (i >= n_new) break;                                       // (workgroup-uniform)
-        const int4 p = par[i];
+        const int4 p = pr[rr];
+        const float4 a4 = a4s[rr], b4 = b4s[rr];
         const bool hasF = p.x != n_old, hasM = p.y != n_old;         // workgroup-uniform
         const int2 mf = hasF ? meta[p.x] : make_int2(0, 0), mm = hasM ? meta[p.y] : make_int2(0, 0);
         const int2 mi = meta_new[i];
         float *trow = T + (long long)i * ldT;
         float *orow = next + (long long)(n_surv + i) * ld_next;
-        // (unconditional loads from a valid row: a select between a global pointer and a zero constant becomes a FLAT load of a
-        // private copy; rows_entry drops the values of a missing parent)
-        const float4 a4 = *reinterpret_cast<const float4 *>(M + (long long)(hasF ? p.x : 0) * ld + q0);
-        const float4 b4 = *reinterpret_cast<const float4 *>(M + (long long)(hasM ? p.y : 0) * ld + q0);
         const float v0 = rows_entry(q0, n_old, make_int2(m01.x, m01.y), a4.x, b4.x, hasF, hasM, p.x, p.y, mf, mm);
         const float v1 = rows_entry(q0 + 1, n_old, make_int2(m01.z, m01.w), a4.y, b4.y, hasF, hasM, p.x, p.y, mf, mm);
         const float v2 = rows_entry(q0 + 2, n_old, make_int2(m23.x, m23.y), a4.z, b4.z, hasF, hasM, p.x, p.y, mf, mm);
@@ -167,32 +176,11 @@ sparse_compact_kernel(const float *__restrict__ M, long long ld, const int *__re
 //   next[n_surv + a][n_surv + b] = RN32(L'(a, f_b)/2 + L'(a, m_b)/2),  L'(a, p) = T[a][p] if rank(p) < rank(a) else 0
 //   next[n_surv + a][n_surv + a] = RN32(1/2 + L(f_a, m_a)/2)
 // Row a of T is staged in LDS when it fits (lds_floats >= n_old), else gathered from L2.
-__global__ void __launch_bounds__(256)
-sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
-                     const int2 *__restrict__ meta_new, const float *__restrict__ T, long long ldT, int n_new, int lds_floats,
-                     float *__restrict__ next, long long ld_next, int n_surv, StaleOut so)
+// partners b > a of new row a; `src` = T[a][.] (global) or its LDS copy -- two instantiations, so that neither gathers through FLAT loads
+template <typename Src>
+__device__ __forceinline__ void newnew_partners(Src src, int a, int n_old, int n_new, int2 ma, const int4 *__restrict__ par,
+                                                const int2 *__restrict__ meta_new, float *__restrict__ orow, const StaleOut &so)
 {
-    extern __shared__ float srow[];
-    const int a = blockIdx.x;
-    const float *trow = T + (long long)a * ldT;
-    // (staging the row costs n_old loads: not worth it for the last rows of the wave, which have few later partners)
-    const bool in_lds = lds_floats >= n_old && 8 * (n_new - a - 1) >= n_old;
-    if (in_lds) {                                                 // (uniform: a and n_new are)
-        const float4 *g4 = reinterpret_cast<const float4 *>(trow);
-        float4 *s4 = reinterpret_cast<float4 *>(srow);
-        for (int k = threadIdx.x; k < (n_old + 3) / 4; k += 256) s4[k] = g4[k];       // (T's pitch is a multiple of 64 floats)
-        __syncthreads();
-    }
-    const float *src = in_lds ? srow : trow;
-    const int2 ma = meta_new[a];
-    float *orow = next + (long long)(n_surv + a) * ld_next + n_surv;
-    if (threadIdx.x == 0) {
-        const int4 p = par[a];
-        double cf = 0.5;
-        if (p.x != n_old && p.y != n_old && (p.x == p.y || key_found(meta[p.x], meta[p.y])))
-            cf += static_cast<double>(half32(M[(long long)p.x * ld + p.y]));
-        orow[a] = static_cast<float>(cf);
-    }
     for (int b0 = a + 1 + threadIdx.x; b0 < n_new; b0 += 4 * 256) {
         int4 p[4];
 #pragma unroll
@@ -213,6 +201,35 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                     const int2 *__restrict__ meta_new, const float *__restrict__ T, long long ldT, int n_new, int lds_floats,
+                     float *__restrict__ next, long long ld_next, int n_surv, StaleOut so)
+{
+    extern __shared__ float srow[];
+    const int a = blockIdx.x;
+    const float *trow = T + (long long)a * ldT;
+    // (staging the row costs n_old loads: not worth it for the last rows of the wave, which have few later partners)
+    const bool in_lds = lds_floats >= n_old && 8 * (n_new - a - 1) >= n_old;
+    if (in_lds) {                                                 // (uniform: a and n_new are)
+        const float4 *g4 = reinterpret_cast<const float4 *>(trow);
+        float4 *s4 = reinterpret_cast<float4 *>(srow);
+        for (int k = threadIdx.x; k < (n_old + 3) / 4; k += 256) s4[k] = g4[k];       // (T's pitch is a multiple of 64 floats)
+        __syncthreads();
+    }
+    const int2 ma = meta_new[a];
+    float *orow = next + (long long)(n_surv + a) * ld_next + n_surv;
+    if (threadIdx.x == 0) {
+        const int4 p = par[a];
+        double cf = 0.5;
+        if (p.x != n_old && p.y != n_old && (p.x == p.y || key_found(meta[p.x], meta[p.y])))
+            cf += static_cast<double>(half32(M[(long long)p.x * ld + p.y]));
+        orow[a] = static_cast<float>(cf);
+    }
+    if (in_lds) newnew_partners(static_cast<const float *>(srow), a, n_old, n_new, ma, par, meta_new, orow, so);
+    else newnew_partners(trow, a, n_old, n_new, ma, par, meta_new, orow, so);
 }
 
 // next[c][r] = next[r][c] for the new rows r >= n_surv and the columns c < n_surv (survivors x new) or c > r
