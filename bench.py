@@ -291,6 +291,9 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS) + ["sparse140", "sparse2k"])
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--storage", default="f32", choices=["f32", "f64"],
+                    help="f64: the secondary Float64 level sweep (GENPHI_FLAG_STORAGE_F64: what gen.f and pairwise phi(i, j) run); "
+                         "N = 1 only, no D2H block, algorithmic bytes count 8 per entry")
     ap.add_argument("--no-d2h", action="store_true", help="skip the device-to-host copy of the end_to_end block")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -355,8 +358,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    f64 = args.storage == "f64"
+    if f64 and world > 1:
+        raise SystemExit("--storage f64 is a single-GPU secondary path")
+    esz = 8.0 if f64 else 4.0
+
     def compute(**kw):
-        return None if empty_shard else pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows, **kw)
+        return None if empty_shard else pl.compute_device(device=local_rank, kernel=args.kernel, rows=rows, storage64=f64, **kw)
 
     # the first call also uploads the index arrays and allocates the level matrices and the result
     t_first = time.perf_counter()
@@ -407,7 +415,7 @@ def main():
         # a launch that computes only part of a level's rows (the sharded last level; the upper levels
         # of a shard, restricted to its ancestors) is credited with the rows it wrote and the same
         # share of the source matrix: byt = 4 (n_k^2 + n_{k+1}^2) * rows / n_{k+1}
-        byt = [4.0 * (a * a + b * b) for a, b in zip(sizes[:-1], sizes[1:])]
+        byt = [esz * (a * a + b * b) for a, b in zip(sizes[:-1], sizes[1:])]
         if level_rows is not None:
             byt = [x * (min(r, b) / b if b else 1.0) for x, r, b in zip(byt, level_rows, sizes[1:])]
         lvl = (level_ms / K) if level_ms is not None and len(byt) else np.zeros(0)
@@ -417,6 +425,8 @@ def main():
         # the kernel that dominates the step: by accumulated time over the level steps of each kind
         modes = pl.step_modes()
         names = {0: "level_full_kernel", 1: "level_split_fast_kernel", 2: "wide level (rows_compact_kernel + ...)"}
+        if f64:                                            # row-staged Float64 kernel up to 10,239-wide cuts, per-entry kernel beyond
+            names = {m: "level_full64_kernel / level_naive64_kernel" for m in (0, 1, 2)}
         by_kernel = {}
         for k, t in enumerate(lvl_kernel):
             small = k < len(lvl_kernel) - 1 and sizes[k] <= 128 and sizes[k + 1] <= 128 and args.kernel == 0
@@ -428,7 +438,7 @@ def main():
         # end to end through the C-ABI: plan (host) + first call (upload, allocation,
         # one sweep) ... + a sweep + the device-to-host copy of the N x N result.  Never `value`.
         end_to_end = {"plan_ms": plan_ms, "first_call_ms": first_call_ms, "sweep_ms": ms_per_step}
-        if world == 1 and not args.no_d2h:
+        if world == 1 and not args.no_d2h and not f64:
             import psutil
             need = n * n * 4
             if psutil.virtual_memory().available > need + (16 << 30):
@@ -454,7 +464,7 @@ def main():
         ceiling, ceiling_src = measured_ceiling()
         traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not f64:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
@@ -462,13 +472,15 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline",
+            "metric": ("Float64 level sweep (secondary path: gen.f, pairwise phi): proband-pairs/s; % HBM roofline on 8-byte entries" if f64
+                       else "proband-pairs/sec for dense Phi (gen.phi), 1e5 probands; % HBM roofline"),
             "value": value, "unit": "proband-pairs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "end_to_end": end_to_end,
             "config": {"workload": f"{args.workload}: {desc}", "n_probands": n, "levels": len(sizes),
-                       "arithmetic": "Float64 accumulation over Float32 level matrices (the reference's contract)", "storage": "f32",
-                       "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes / 1e9,
+                       "arithmetic": ("Float64 level matrices, Float64 accumulation (src/compute.jl:66-95 contract)" if f64 else
+                                      "Float64 accumulation over Float32 level matrices (the reference's contract)"), "storage": args.storage,
+                       "max_cut": max(sizes) if sizes else 0, "algorithmic_GB": pl.algorithmic_bytes * esz / 4.0 / 1e9,
                        "parallelism": f"final-level row shards x{world}, upper levels replicated" if world > 1 else "1 GPU",
                        "kernel_ms_per_step": kernel_ms / K, "proband_order_pass_ms": perm_ms / K,
                        "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
@@ -486,14 +498,17 @@ def main():
                          "traffic_stale": traffic_stale,
                          "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
+                         "largest_level": ({"step": int(np.argmax(byt)), "GB": max(byt) / 1e9, "ms": float(lvl_kernel[int(np.argmax(byt))]),
+                                            "frac": max(byt) / (float(lvl_kernel[int(np.argmax(byt))]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                           if len(byt) and float(lvl_kernel[int(np.argmax(byt))]) > 0 else None),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),
-                         "whole_step_frac": (pl.algorithmic_bytes / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         "whole_step_frac": (pl.algorithmic_bytes * esz / 4.0 / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if kernel_ms > 0 else None,
                          # host wall clock per sweep without per-level events (hipGraph replay for >= 8 level steps)
                          "graph_replay_ms_per_step": replay_ms,
-                         "graph_replay_frac": (pl.algorithmic_bytes / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None},
+                         "graph_replay_frac": (pl.algorithmic_bytes * esz / 4.0 / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None},
         }
-        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
         print(json.dumps(out), flush=True)
     pl.close()

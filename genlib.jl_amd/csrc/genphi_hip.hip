@@ -1239,56 +1239,92 @@ __global__ void level_naive64_kernel(const double *__restrict__ psi, long long l
 }
 
 // Float64 storage, cuts whose two source rows fit in LDS (2 x 8 bytes x (n_prev + 1) <= 160 KB): the FULL
-// kernel's shape -- one workgroup per output row, both source rows staged whole with 16-byte coalesced loads,
-// four 8-byte LDS gathers per entry, coalesced row stores -- with the reference's grouping (src/compute.jl:66-95
-// climbs the higher-ranked individual first) and no rounding to Float32.  Same arguments as level_naive64_kernel.
+// kernel's shape -- both source rows of an output row staged whole with 16-byte coalesced loads, four 8-byte LDS
+// gathers per entry, coalesced row stores -- with the reference's grouping (src/compute.jl:66-95 climbs the
+// higher-ranked individual first) and no rounding to Float32.  Same arguments as level_naive64_kernel + the number
+// of rows.  PERSISTENT: a workgroup walks rows w = blockIdx.x, + gridDim.x, ... and
+//   - owns the same columns in every row, so their index words (sources, rank word, member) are loaded ONCE into
+//     registers (they were three dependent global loads per entry),
+//   - has the NEXT row pair in flight into registers while the current one is gathered from LDS (rows of 7k+ members
+//     leave room for one workgroup per CU only: nothing else would hide the load latency).
+typedef double d2_t __attribute__((ext_vector_type(2)));   // (HIP's d2_t is a struct of unions: arrays of it stay in scratch)
+constexpr int kF64Cols = 20;      // columns per thread: ceil(10 304 / 512)  (ld of the widest cut whose rows fit)
+constexpr int kF64Pre = 10;       // d2_t pieces per source row and thread: ceil(10 240 / 2 / 512)
 __global__ void __launch_bounds__(512)
 level_full64_kernel(const double *__restrict__ psi, long long ld_prev, int n_prev, double *__restrict__ out, long long ld,
                     const int *__restrict__ srcA, const int *__restrict__ srcB, const int *__restrict__ ord,
                     const int *__restrict__ rows, const int *__restrict__ out_rows, const int *__restrict__ colmap, int n_cols,
-                    int lds_row)
+                    int lds_row, int n_rows)
 {
     extern __shared__ double lds64[];
     double *sA = lds64, *sB = lds64 + lds_row;
-    const int w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int i = rows ? rows[w] : w;
-    const long long orow = out_rows ? out_rows[w] : i;
-    const int Ai = srcA[i], Bi = srcB[i], oi = ord[i];
-    const bool hasB = Bi != n_prev;
-    {
-        const double2 *a2 = reinterpret_cast<const double2 *>(psi + (long long)Ai * ld_prev);
-        const double2 *b2 = reinterpret_cast<const double2 *>(psi + (long long)Bi * ld_prev);
-        double2 *sA2 = reinterpret_cast<double2 *>(sA), *sB2 = reinterpret_cast<double2 *>(sB);
-        const int nvec = lds_row >> 1;
-        for (int base = tid; base < nvec; base += 4 * nt) {
-            double2 ra[4], rb[4];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    unsigned pkj[kF64Cols];
+    int oj[kF64Cols], jmv[kF64Cols];
+    const int j0 = blockIdx.y * nt * kF64Cols;           // this workgroup's column chunk (outputs wider than 512 x 20 columns take several)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int q = min(base + k * nt, nvec - 1); ra[k] = a2[q]; rb[k] = hasB ? b2[q] : make_double2(0.0, 0.0); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int q = min(base + k * nt, nvec - 1); sA2[q] = ra[k]; sB2[q] = rb[k]; }
-        }
-    }
-    __syncthreads();
-    const bool new_i = oi < 0;
-    const int ord_i = oi & kOrdMask;
-    double *orowp = out + orow * ld;
-    for (int j = tid; j < ld; j += nt) {
-        double v = 0.0;
+    for (int k = 0; k < kF64Cols; ++k) {
+        const int j = j0 + tid + k * nt;
+        pkj[k] = 0; oj[k] = 0; jmv[k] = -1;
         if (j < n_cols) {
             const int jm = colmap ? colmap[j] : j;
-            const int Aj = srcA[jm], Bj = srcB[jm], oj = ord[jm];
-            if (jm == i && new_i) {
-                v = 0.5 + 0.5 * sA[Bi];
-            } else {
-                const double sc = (new_i ? 0.5 : 1.0) * (oj < 0 ? 0.5 : 1.0);
-                const double a = sA[Aj], b = sA[Bj], c = sB[Aj], d = sB[Bj];
-                const bool i_hi = ord_i > (oj & kOrdMask);
-                const double x = i_hi ? b : c, y = i_hi ? c : b;
-                v = ((a + x) + (y + d)) * sc;
-            }
+            jmv[k] = jm; pkj[k] = static_cast<unsigned>(srcA[jm]) | static_cast<unsigned>(srcB[jm]) << 16; oj[k] = ord[jm];
         }
-        orowp[j] = v;
     }
+    const int nvec = lds_row >> 1;
+    d2_t ra[kF64Pre], rb[kF64Pre];
+#define GENPHI_F64_FETCH(W)                                                                                                    \
+    {                                                                                                                          \
+        const int fi = rows ? rows[W] : (W);                                                                                   \
+        const d2_t *a2 = reinterpret_cast<const d2_t *>(psi + (long long)srcA[fi] * ld_prev);                            \
+        const d2_t *b2 = reinterpret_cast<const d2_t *>(psi + (long long)srcB[fi] * ld_prev);  /* "none" = the zero row */ \
+        _Pragma("unroll") for (int k = 0; k < kF64Pre; ++k) { const int q = min(tid + k * nt, nvec - 1); ra[k] = a2[q]; rb[k] = b2[q]; } \
+    }
+    int w = blockIdx.x;
+    if (w >= n_rows) return;
+    GENPHI_F64_FETCH(w)
+    for (; w < n_rows; w += gridDim.x) {
+        __syncthreads();                                  // the previous row's gathers are done
+        {
+            d2_t *sA2 = reinterpret_cast<d2_t *>(sA), *sB2 = reinterpret_cast<d2_t *>(sB);
+#pragma unroll
+            for (int k = 0; k < kF64Pre; ++k) { const int q = tid + k * nt; if (q < nvec) { sA2[q] = ra[k]; sB2[q] = rb[k]; } }
+        }
+        const int i = rows ? rows[w] : w;
+        const long long orow = out_rows ? out_rows[w] : i;
+        const int Bi = srcB[i], oi = ord[i];
+        if (w + (int)gridDim.x < n_rows) GENPHI_F64_FETCH(w + (int)gridDim.x)      // in flight behind the gathers
+        __syncthreads();
+        const bool new_i = oi < 0;
+        const int ord_i = oi & kOrdMask;
+        double *orowp = out + orow * ld;
+        unsigned z1 = 0;                                  // opaque zero: the LDS addresses of the 20 columns are row-invariant, and hipcc
+        asm volatile("" : "+s"(z1));                      // would keep all 80 of them in registers across the row loop (spills)
+#pragma unroll
+        for (int k = 0; k < kF64Cols; ++k) {
+            const int j = j0 + tid + k * nt;
+            if (j >= ld) break;
+            double v = 0.0;
+            if (jmv[k] >= 0) {
+                const unsigned pkz = pkj[k] ^ z1;
+                const int ojz = oj[k] ^ static_cast<int>(z1);
+                const unsigned Aj = pkz & 0xffffu, Bj = pkz >> 16;
+                if (jmv[k] == i && new_i) {
+                    v = 0.5 + 0.5 * sA[Bi];
+                } else {
+                    const double sc = (new_i ? 0.5 : 1.0) * (ojz < 0 ? 0.5 : 1.0);
+                    const double a = sA[Aj], b = sA[Bj], c = sB[Aj], d = sB[Bj];
+                    const bool i_hi = ord_i > (ojz & kOrdMask);
+                    const double x = i_hi ? b : c, y = i_hi ? c : b;
+                    v = ((a + x) + (y + d)) * sc;
+                }
+            }
+            orowp[j] = v;
+            if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // two columns' gathers in flight, not twenty (registers)
+        }
+    }
+    (void)n_prev;
+#undef GENPHI_F64_FETCH
 }
 
 __global__ void half_identity64_kernel(double *m, long long ld, int n, const int *out_rows, int n_rows, const int *colmap)
@@ -2540,7 +2576,7 @@ static int ensure_doubles(double **ptr, size_t *have, size_t need)
 
 // The whole sweep with Float64 level matrices (see level_naive64_kernel): rows [r0, r1) of the
 // proband matrix end up in p->result64 (row pitch = pitch of the last cut).
-static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel)
+static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genphi_stats *stats, bool timing)
 {
     const Plan &pl = p->plan;
     const int L = pl.n_levels, n_steps = L - 1;
@@ -2571,7 +2607,13 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel)
         HIP_TRY(hipStreamSynchronize(p->stream));
         return GENPHI_OK;
     }
+    if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
+    if (timing)
+        while (static_cast<int>(p->events.size()) < n_steps + 3) {
+            hipEvent_t e; HIP_TRY(hipEventCreate(&e)); p->events.push_back(e);
+        }
     const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
+    if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
     HIP_TRY(hipMemsetAsync(p->buf64[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(double), p->stream));
     hipLaunchKernelGGL(half_identity64_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0, p->stream, p->buf64[0],
                        static_cast<long long>(ld0), static_cast<int>(n0), static_cast<const int *>(nullptr), static_cast<int>(n0),
@@ -2592,10 +2634,15 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel)
         if (kernel != 1 && lds64 <= 160 * 1024 && rows_n > 0) {
             // both Float64 source rows fit in LDS (cuts up to 10,239 members): the row-staged kernel
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_full64_kernel), lds64));
-            const int bs = st.n <= 512 ? 64 : (st.n <= 2048 ? 256 : 512);
-            hipLaunchKernelGGL(level_full64_kernel, dim3(static_cast<unsigned>(rows_n)), dim3(bs), lds64, p->stream, psi,
+            // (columns per thread <= kF64Cols, row pieces per thread <= kF64Pre for each of these block sizes)
+            const int bs = st.ld <= 64 * kF64Cols && lds_row64 <= 2 * 64 * kF64Pre ? 64 : (st.ld <= 256 * kF64Cols && lds_row64 <= 2 * 256 * kF64Pre ? 256 : 512);
+            const int chunks = static_cast<int>((st.ld + bs * kF64Cols - 1) / (bs * kF64Cols));
+            // resident workgroups per CU: LDS, and the kernel's ~240 VGPRs (two waves per SIMD)
+            const int per_cu = static_cast<int>(std::min<size_t>(512 / bs, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds64, 1))));
+            const int grid = std::min(rows_n, std::max(1, p->n_cus * per_cu / chunks));
+            hipLaunchKernelGGL(level_full64_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(chunks)), dim3(bs), lds64, p->stream, psi,
                                static_cast<long long>(st.ld_prev), static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), d.srcA, d.srcB,
-                               d.ord, k_rows, k_orows, k_colmap, static_cast<int>(st.n), lds_row64);
+                               d.ord, k_rows, k_orows, k_colmap, static_cast<int>(st.n), lds_row64, rows_n);
         } else {
             dim3 grid(static_cast<unsigned>(rows_n), static_cast<unsigned>((st.ld + 255) / 256));
             hipLaunchKernelGGL(level_naive64_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(st.ld_prev),
@@ -2605,9 +2652,22 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel)
         HIP_TRY(hipGetLastError());
         if (!last)           // the all-zero "none" row of this level
             HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(double), p->stream));
+        if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
+        if (stats && s < GENPHI_MAX_STAT_LEVELS) stats->level_rows[s] = rows_n;
     }
     (void)N;
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (timing) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->events[0], p->events[n_steps]));
+        stats->total_ms = ms;
+        for (int s = 0; s < n_steps; ++s) {
+            HIP_TRY(hipEventElapsedTime(&ms, p->events[s], p->events[s + 1]));
+            stats->level_ms[s] = ms;
+        }
+        stats->final_ms = stats->level_ms[n_steps - 1];
+        stats->timed = 1;
+    }
     return GENPHI_OK;
 }
 
@@ -2638,7 +2698,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     p->res_f64 = opts && (opts->flags & GENPHI_FLAG_STORAGE_F64);
     if (p->res_f64) {
         p->res_ld = pl.ld[L - 1];
-        return compute_f64(p, r0, r1, kernel);
+        return compute_f64(p, r0, r1, kernel, stats, timing);
     }
     if (p->popt.indices_only) return fail(GENPHI_ERR_ARG, "internal: an indices-only plan serves Float64-storage sweeps only");
     rc = ensure_level_buffers(p);

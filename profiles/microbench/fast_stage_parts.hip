@@ -14,12 +14,13 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off fast_stage_parts.hip -o fast_stage_parts
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 constexpr int ROWF = 30976, LD = 31040, CPT = 40, STG = 16, NT = 512, STAGES = 512, OUTW = NT * CPT;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float *__restrict__ out, unsigned seed, int n_rows, int n_out_rows)
+__global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float *__restrict__ out, unsigned seed, int n_rows, int n_out_rows, int share)
 {
     extern __shared__ float sR[];
     for (int i = threadIdx.x; i < LD; i += NT) sR[i] = 1.0f / (1 + (i & 1023));
@@ -33,7 +34,9 @@ __global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float
         pk[k] = A | B << 16; pab[k] = (static_cast<double>(sR[A]) + static_cast<double>(sR[B])) * 0.25;
     }
     unsigned tl = threadIdx.x;
-    unsigned row = (blockIdx.x * 7919u) % n_rows;
+    // workgroups b, b + 8, b + 16, ... sit on one XCD; `share` consecutive ones of them walk the same rows (as the column chunks
+    // of one work item do in the product kernel): their loads can hit L2
+    unsigned row = (((blockIdx.x >> 3) / share * 8 + (blockIdx.x & 7)) * 7919u) % n_rows;
     f4 pre[STG];
     float acc = 0.f;
     constexpr bool kLoads = MODE >= 5, kStage = MODE >= 4;
@@ -82,27 +85,31 @@ __global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float
     if (acc == 12345.f) out[0] = acc;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int grid = argc > 1 ? atoi(argv[1]) : 256;       // workgroups (default: one per CU); 128 = half the chip: less bandwidth contention
+    printf("%d workgroups\n", grid);
     const int n_rows = 30976, n_out_rows = 16384;      // a 3.8 GB source level, 1.7 GB of output rows
     float *psi, *out;
     (void)hipMalloc(&psi, (size_t)n_rows * LD * 4); (void)hipMalloc(&out, (size_t)n_out_rows * OUTW * 4);
     (void)hipMemset(psi, 0, (size_t)n_rows * LD * 4);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    void (*ks[])(const float *, float *, unsigned, int, int) = {stage<0>, stage<1>, stage<2>, stage<3>, stage<4>, stage<5>, stage<6>, stage<7>};
+    void (*ks[])(const float *, float *, unsigned, int, int, int) = {stage<0>, stage<1>, stage<2>, stage<3>, stage<4>, stage<5>, stage<6>, stage<7>};
     const char *names[] = {"gathers only", "VALU only", "gathers + VALU", "+ row stores", "+ LDS staging, 2 barriers", "+ loads of the next row",
                            "same, every load hits (row 0)", "MODE 5 + vmcnt(0) before the LDS writes"};
     for (int m = 0; m < 8; ++m) {
         (void)hipFuncSetAttribute((const void *)ks[m], hipFuncAttributeMaxDynamicSharedMemorySize, LD * 4);
-        float best = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
-            (void)hipEventRecord(a);
-            hipLaunchKernelGGL(ks[m], dim3(256), dim3(NT), LD * 4, 0, psi, out, 7u, n_rows, n_out_rows);
-            (void)hipEventRecord(b); (void)hipEventSynchronize(b);
-            float ms; (void)hipEventElapsedTime(&ms, a, b);
-            if (ms < best) best = ms;
+        for (int share = 1; share <= (m == 5 || m == 7 ? 4 : 1); share *= 2) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(a);
+                hipLaunchKernelGGL(ks[m], dim3(grid), dim3(NT), LD * 4, 0, psi, out, 7u, n_rows, n_out_rows, share);
+                (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+                float ms; (void)hipEventElapsedTime(&ms, a, b);
+                if (ms < best) best = ms;
+            }
+            printf("%-42s %s %8.3f ms = %6.3f us per stage\n", names[m], share == 1 ? "          " : (share == 2 ? "(2 share) " : "(4 share) "), best, best * 1e3 / STAGES);
         }
-        printf("%-34s %8.3f ms = %6.3f us per stage\n", names[m], best, best * 1e3 / STAGES);
     }
     return 0;
 }

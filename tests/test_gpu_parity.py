@@ -796,6 +796,66 @@ def test_pairwise_phi_float64(gen, oracle):
     pl.close()
 
 
+@pytest.mark.gpu
+def test_float64_sweep_kernels(gen, oracle, monkeypatch):
+    """The Float64 level sweep (GENPHI_FLAG_STORAGE_F64; src/compute.jl:66-95 arithmetic): the persistent row-staged
+    kernel (level_full64_kernel: column index words in registers, next row pair in flight) against the per-entry
+    kernel on the same plans -- every block size, several column chunks, a final level kept in [dragged, new] order
+    (forced WIDE plan: colmap), row shards -- and against the oracle's literal pairwise recursion on samples."""
+    from genlib_jl_amd import synth
+    rng = np.random.default_rng(11)
+
+    def both(ind, fa, mo, pro, samples, rows=None):
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": np.ones(len(ind), dtype=np.int64)})
+        pl = gen.plan(ped, pro)
+        pl.compute_device(storage64=True, rows=rows)
+        a = pl.result_to_host_f64().copy()
+        pl.compute_device(storage64=True, kernel=1, rows=rows)
+        b = pl.result_to_host_f64()
+        assert a.dtype == np.float64 and np.array_equal(a, b), np.abs(a - b).max()
+        r0 = rows[0] if rows else 0
+        op = oracle.Pedigree(ped.ind, ped.father, ped.mother)
+        for i, j in samples:
+            if r0 <= i < r0 + a.shape[0]:
+                assert a[i - r0, j] == op.phi_pair(int(pro[i]), int(pro[j])), (i, j)
+        pl.close()
+        return a
+
+    # (a) overlapping generations (dragged members, one-parent rows), cuts of a few thousand: 256- and 512-thread workgroups
+    ind, fa, mo, sex, pro = synth.random_mating(20000, 1500, 8, skip_permille=100, seed=5)
+    sm = [(int(x), int(y)) for x, y in zip(rng.integers(0, 1500, 12), rng.integers(0, 1500, 12))] + [(7, 7)]
+    full = both(ind, fa, mo, pro, sm)
+    assert np.array_equal(full, full.T) and np.count_nonzero(full) > 1500
+    part = both(ind, fa, mo, pro, sm, rows=(700, 1100))
+    assert np.array_equal(part, full[700:1100])
+    # (b) the same through a plan whose last step is WIDE: the last cut stays in [dragged, new] order (colmap)
+    monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", "1024")
+    monkeypatch.setenv("GENPHI_NO_SMALL", "1")
+    wide = both(ind, fa, mo, pro, sm[:4])
+    assert np.array_equal(wide, full)
+    monkeypatch.delenv("GENPHI_LDS_CAP_FLOATS"); monkeypatch.delenv("GENPHI_NO_SMALL")
+    # (c) an output far wider than the cut above it: 11 000 probands from 60 parents -> two column chunks of 512 x 20
+    n_par, n_pro = 60, 11000
+    ind = np.arange(1, n_par + n_pro + 1, dtype=np.int64)
+    fa = np.zeros(len(ind), dtype=np.int64); mo = np.zeros(len(ind), dtype=np.int64)
+    fa[n_par:] = 1 + 2 * rng.integers(0, n_par // 2, n_pro)
+    mo[n_par:] = 2 + 2 * rng.integers(0, n_par // 2, n_pro)
+    mo[n_par + 5] = 0                                              # a one-parent proband
+    pro = ind[n_par:]
+    sm = [(int(x), int(y)) for x, y in zip(rng.integers(0, n_pro, 10), rng.integers(0, n_pro, 10))] + [(10500, 10999), (10999, 10999), (5, 5)]
+    got = both(ind, fa, mo, pro, sm)
+    assert got.shape == (n_pro, n_pro) and np.array_equal(got[:300, 10240:], got[10240:, :300].T)
+    # (d) tiny cuts: 64-thread workgroups (geneaJi, every individual a proband of its own sweep)
+    ped = gen.genealogy(gen.geneaJi)
+    op = oracle.Pedigree.from_file(gen.geneaJi)
+    pl = gen.plan(ped, ped.ind[-9:])
+    pl.compute_device(storage64=True)
+    m = pl.result_to_host_f64()
+    want = np.array([[op.phi_pair(int(x), int(y)) for y in ped.ind[-9:]] for x in ped.ind[-9:]])
+    assert np.array_equal(m, want)
+    pl.close()
+
+
 def test_branching_then_phi(gen, oracle):
     """SURVEY 8(f) row 2 through the GPU: pruning the pedigree to the probands' ancestors
     (gen.branching, src/extract.jl:65-186) must not change gen.phi."""
