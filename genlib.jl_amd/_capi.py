@@ -40,7 +40,7 @@ class GenphiStats(C.Structure):
 
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info",
+    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
     "genphi_plan_algorithmic_bytes", "genphi_plan_step_walk", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
@@ -81,6 +81,8 @@ def lib():
         L.genphi_plan_step_mode.restype = C.c_int
         L.genphi_plan_step_info.argtypes = [C.c_void_p, C.c_int32, _I64P]
         L.genphi_plan_step_info.restype = C.c_int
+        L.genphi_plan_step_slots.argtypes = [C.c_void_p, C.c_int32, _I64P]
+        L.genphi_plan_step_slots.restype = C.c_int
         _I32P = C.POINTER(C.c_int32)
         if hasattr(L, "genphi_plan_step_walk"):            # (absent from older builds used in same-box A/B runs)
             L.genphi_plan_step_walk.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P, _I32P, _I32P, _I32P]
@@ -275,6 +277,15 @@ class PhiPlan:
         """(mode, dragged members, distinct parents of the new members, new x new sub-step mode) of a level step."""
         out = (C.c_int64 * 4)()
         rc = lib().genphi_plan_step_info(self._h, int(step), out)
+        if rc:
+            _raise(rc)
+        return tuple(int(x) for x in out)
+
+    def step_slots(self, step):
+        """(flags: 1 = the step writes its cut in place | 2 = it reads a cut stored by slot, slot capacity, first slot and
+        reserved slots of the new members) of a level step; zeros unless WIDE steps keep their members in place."""
+        out = (C.c_int64 * 4)()
+        rc = lib().genphi_plan_step_slots(self._h, int(step), out)
         if rc:
             _raise(rc)
         return tuple(int(x) for x in out)

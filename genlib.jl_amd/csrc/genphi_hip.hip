@@ -1007,6 +1007,44 @@ rows_compact_kernel(const float *__restrict__ psi, long long ld_prev, int none, 
     if (cert_out && ck < cert_thresh) cert_out[d.z] = 1;
 }
 
+// A WIDE level that stays in place (LevelStep::stay): the new x dragged block of the new rows, written at the dragged members' own
+// columns (their slots):  m[z(w)][idx[k]] = RN32((m[A(w)][idx[k]] + m[B(w)][idx[k]]) / 2),  k < n_idx.  Source and destination are
+// the same matrix (no __restrict__): the new rows' slots hold no member of the source cut.  rowdesc as in rows_compact_kernel.
+__global__ void __launch_bounds__(256)
+rows_avg_kernel(const float *m, long long ld, int none, const int4 *__restrict__ rowdesc, const int *__restrict__ idx, int n_idx,
+                float *mo, int *__restrict__ cert_out, unsigned cert_thresh)
+{
+    constexpr int U = 8;
+    const int4 d = rowdesc[blockIdx.x];
+    const float *ra = m + (long long)d.x * ld;
+    const float *rb = m + (long long)d.y * ld;
+    float *o = mo + (long long)d.z * ld;
+    const double sc = d.w == 0 ? 1.0 : 0.5;
+    const int k0 = blockIdx.y * (256 * U) + threadIdx.x;
+    int q[U];
+    float a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = idx[min(k0 + u * 256, n_idx - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = ra[q[u]];
+    const bool two = d.y != none;                              // uniform
+    if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = rb[q[u]];
+    }
+    unsigned ck = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float v = two ? static_cast<float>((static_cast<double>(a[u]) + static_cast<double>(b[u])) * sc)
+                            : static_cast<float>(static_cast<double>(a[u]) * sc);
+        if (k0 + u * 256 < n_idx) {
+            ck = min(ck, cert_key(v));
+            o[q[u]] = v;
+        }
+    }
+    if (cert_out && ck < cert_thresh) cert_out[d.z] = 1;
+}
+
 // The dragged rows of a WIDE level in ONE pass over their source row: row j of the cut is the row of
 // the same member in the previous cut,
 //   columns [0, nd)   out[j][k] = Psi[a_j][idx[k]]                           (stream compaction)
@@ -1167,11 +1205,12 @@ transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows
 }
 
 // zero padding of a level matrix: columns [n, ld) of rows 0..n-1 and the whole "none" row n
-__global__ void __launch_bounds__(256) pad_zero_kernel(float *__restrict__ m, long long ld, int n)
+// (width <= ld: the columns the level owns -- the entry cut of an in-place run has the run's pitch, but only its own width is padded)
+__global__ void __launch_bounds__(256) pad_zero_kernel(float *__restrict__ m, long long ld, int n, long long width)
 {
     const int r = blockIdx.x;
     float *row = m + (long long)r * ld;
-    for (long long j = (r < n ? n : 0) + threadIdx.x; j < ld; j += 256) row[j] = 0.f;
+    for (long long j = (r < n ? n : 0) + threadIdx.x; j < width; j += 256) row[j] = 0.f;
 }
 
 __global__ void level_naive_kernel(const LevelArgs p)
@@ -1584,6 +1623,9 @@ constexpr size_t kIdxPad = 32 * 1024;
 struct Tuning {
     int lds_cap_floats = 0;        // GENPHI_LDS_CAP_FLOATS   test: LDS budget for staged rows (forces SPLIT / WIDE on small inputs)
     int full_max_floats = -1;      // GENPHI_FULL_MAX_FLOATS  tuning: FULL vs SPLIT threshold (row length in floats)
+    bool no_stay = false;          // GENPHI_NO_STAY          A/B + test: WIDE levels never stay in place (every level is copied into the other buffer)
+    int stay_max_slots = 0;        // GENPHI_STAY_MAX_SLOTS   test: largest slot capacity of an in-place run (default: planner.h)
+    int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
                                    //                         larger: the walk chains from hub to hub (16-20 % fewer staged rows, measured no faster:
@@ -1614,6 +1656,9 @@ static Tuning tuning_from_env()
     auto has = [](const char *name) { return std::getenv(name) != nullptr; };
     t.lds_cap_floats = geti("GENPHI_LDS_CAP_FLOATS", 0);
     t.full_max_floats = geti("GENPHI_FULL_MAX_FLOATS", -1);
+    t.no_stay = geti("GENPHI_NO_STAY", 0) != 0;
+    t.stay_max_slots = geti("GENPHI_STAY_MAX_SLOTS", 0);
+    t.stay_headroom = geti("GENPHI_STAY_HEADROOM", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -1663,6 +1708,8 @@ struct DeviceStep {
     int4 *rowdesc = nullptr, *pardesc = nullptr;
     int *parents = nullptr, *newrows = nullptr;
     int *pstart = nullptr;     // drag_rows_kernel: first parent of each chunk of 8192 dragged columns
+    int *idx = nullptr;        // source column of every dragged member (= srcA; the sources' SLOTS when the source cut is stored by slot:
+                               // then rowdesc / pardesc / parents hold slots too, see LevelStep::src_slots)
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -1741,6 +1788,12 @@ struct genphi_plan {
     int64_t shard_cap = 0, shard_r0 = -1, shard_r1 = -1;
     float *buf[2] = {nullptr, nullptr};
     size_t buf_floats[2] = {0, 0};
+    // which of the two level buffers holds cut c: alternating, except that a WIDE step that stays in place (LevelStep::stay)
+    // writes into its source's buffer.  buf_of[0]: with in-place steps (the product sweep), buf_of[1]: plain alternation (the
+    // per-entry kernel = 1 sweep, which knows no slots).  cert_cut[c]: the cut whose certificate words cut c shares in the
+    // product sweep (the entry cut of its in-place run; c itself otherwise).
+    std::vector<int> buf_of[2], cert_cut;
+    bool stay_active = false;                    // this sweep keeps WIDE levels in place (set per compute call)
     float *result = nullptr, *final_tmp = nullptr;
     // Float64-storage sweeps (gen.f, pairwise phi): own level matrices and result
     double *buf64[2] = {nullptr, nullptr}, *result64 = nullptr;
@@ -1820,6 +1873,9 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     p->popt.indices_only = indices_only;
     if (p->tun.lds_cap_floats >= 16) p->popt.lds_cap_floats = p->tun.lds_cap_floats;
     if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
+    p->popt.no_stay = p->tun.no_stay;
+    if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
+    if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     std::string err;
     int rc;
     try {
@@ -1862,6 +1918,16 @@ int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info)
     const LevelStep &s = plan->plan.steps[step];
     info[0] = s.mode; info[1] = s.n_dragged; info[2] = static_cast<int64_t>(s.parents.size());
     info[3] = s.mode != genphi::kModeWide ? -1 : (s.nn.empty() ? 3 : s.nn[0].mode);
+    return GENPHI_OK;
+}
+int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
+{
+    if (!plan || !info || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size()))
+        return fail(GENPHI_ERR_ARG, "genphi_plan_step_slots: bad argument");
+    const LevelStep &s = plan->plan.steps[step];
+    info[0] = (s.stay ? 1 : 0) | (s.src_slots ? 2 : 0);
+    info[1] = s.stay ? plan->plan.ld[step + 1] : (s.src_slots ? s.P : 0);
+    info[2] = s.p0; info[3] = s.npad;
     return GENPHI_OK;
 }
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
@@ -1948,7 +2014,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         }
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
-                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int));
+                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
@@ -1978,17 +2044,22 @@ static int upload_plan_impl(genphi_plan *p, int device)
         }
         if (s.mode == genphi::kModeSplit) put_groups(step_groups[k], d.groups, put);
         if (s.mode == genphi::kModeWide) {
-            const int none = static_cast<int>(s.n_prev);
+            // (a source cut stored by slot: sources, parents and "none" are slots of its P x P matrix; a step that stays in
+            // place writes row r of its cut to the member's slot)
+            const int none = s.src_slots ? s.P : static_cast<int>(s.n_prev);
+            const int32_t *sA = s.src_slots ? s.absA.data() : s.srcA.data(), *sB = s.src_slots ? s.absB.data() : s.srcB.data();
+            const int32_t *par = s.src_slots ? s.parents_abs.data() : s.parents.data();
             std::vector<int4> rd(s.n), pd(s.parents.size());
             std::vector<int> nr(s.n - s.n_dragged);
             for (int64_t r = 0; r < s.n; ++r)              // dragged: weight 1; new: weight 1/2 (columns here are dragged: weight 1)
-                rd[r] = make_int4(s.srcA[r], s.srcB[r], static_cast<int>(r), s.ord[r] < 0 ? -1 : 0);
-            for (size_t u = 0; u < s.parents.size(); ++u) pd[u] = make_int4(s.parents[u], none, static_cast<int>(u), 0);
+                rd[r] = make_int4(sA[r], sB[r], s.stay ? s.out_slots[r] : static_cast<int>(r), s.ord[r] < 0 ? -1 : 0);
+            for (size_t u = 0; u < s.parents.size(); ++u) pd[u] = make_int4(par[u], none, static_cast<int>(u), 0);
             for (size_t r = 0; r < nr.size(); ++r) nr[r] = static_cast<int>(s.n_dragged + r);
             d.rowdesc = reinterpret_cast<int4 *>(put(rd.data(), rd.size() * sizeof(int4)));
             d.pardesc = reinterpret_cast<int4 *>(put(pd.data(), pd.size() * sizeof(int4)));
-            d.parents = reinterpret_cast<int *>(put(s.parents.data(), s.parents.size() * sizeof(int)));
+            d.parents = reinterpret_cast<int *>(put(par, s.parents.size() * sizeof(int)));
             d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
+            d.idx = reinterpret_cast<int *>(put(sA, s.n_dragged * sizeof(int)));
             // drag_rows_kernel: parents inside the source window of each chunk of 8192 dragged columns
             const int64_t chunk = 8192, nch = (s.n_dragged + chunk - 1) / chunk;
             std::vector<int> ps(nch + 1, 0);
@@ -2012,10 +2083,18 @@ static int upload_plan_impl(genphi_plan *p, int device)
     {   // certificates: words [cert_off[c], cert_off[c] + n_c] belong to cut c (incl. its "none" row)
         p->cert_off.assign(pl.n_levels + 1, 0);
         size_t w = 0;
+        p->cert_cut.assign(pl.n_levels + 1, 0);
+        p->buf_of[0].assign(pl.n_levels, 0); p->buf_of[1].assign(pl.n_levels, 0);
         for (int c = 0; c < pl.n_levels; ++c) {
             p->cert_off[c] = w;
-            w += static_cast<size_t>(pl.cut_sizes[c]) + 1;
+            // (a cut stored by slot -- the source of a step with src_slots -- has one word per slot + the "none" row P)
+            const bool by_slot = c < static_cast<int>(pl.steps.size()) && pl.steps[c].src_slots;
+            w += (by_slot ? static_cast<size_t>(pl.steps[c].P) : static_cast<size_t>(pl.cut_sizes[c])) + 1;
+            const bool stays = c >= 1 && pl.steps[c - 1].stay;
+            p->cert_cut[c] = stays ? p->cert_cut[c - 1] : c;
+            if (c >= 1) { p->buf_of[0][c] = stays ? p->buf_of[0][c - 1] : 1 - p->buf_of[0][c - 1]; p->buf_of[1][c] = c & 1; }
         }
+        p->cert_cut[pl.n_levels] = pl.n_levels;
         p->cert_off[pl.n_levels] = w;
         p->cert_words = w;
         HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert), std::max<size_t>(w, 1) * sizeof(int)));
@@ -2041,8 +2120,12 @@ static int ensure_level_buffers_impl(genphi_plan *p)
     const Plan &pl = p->plan;
     // ping-pong buffers for the intermediate cuts 0..L-2
     size_t need[2] = {0, 0};
-    for (int c = 0; c + 1 < pl.n_levels; ++c)
-        need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]) + kTailPadFloats);
+    for (int c = 0; c + 1 < pl.n_levels; ++c) {
+        // a cut stored by slot (the cuts of an in-place run of WIDE steps): P + 1 rows of pitch P = ld[c]
+        const bool by_slot = pl.steps[c].src_slots;
+        const size_t fl = static_cast<size_t>(((by_slot ? static_cast<int64_t>(pl.steps[c].P) : pl.cut_sizes[c]) + 1) * pl.ld[c]) + kTailPadFloats;
+        for (int v = 0; v < 2; ++v) need[p->buf_of[v][c]] = std::max(need[p->buf_of[v][c]], fl);
+    }
     for (int b = 0; b < 2; ++b) {
         if (need[b]) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->buf[b]), need[b] * sizeof(float)));
@@ -2260,8 +2343,9 @@ static LevelCtx main_ctx(genphi_plan *p, int step)
 {
     LevelCtx c;
     c.s = &p->plan.steps[step]; c.d = &p->dsteps[step]; c.slot = step;
-    c.cert_prev = p->d_cert + p->cert_off[step];
-    c.cert_out = p->d_cert + p->cert_off[step + 1];      // (the last level's have no reader: harmless)
+    // (cuts of an in-place run share the words of the run's entry cut: a member keeps its slot)
+    c.cert_prev = p->d_cert + p->cert_off[p->stay_active ? p->cert_cut[step] : step];
+    c.cert_out = p->d_cert + p->cert_off[p->stay_active ? p->cert_cut[step + 1] : step + 1];      // (the last level's have no reader: harmless)
     c.identity = identity_source(step, p->tun);
     c.no_none_row = false;
     c.dbg = (p->tun.dbg_step >= 0 ? p->tun.dbg_step : static_cast<int>(p->plan.steps.size()) - 1) == step;     // default: the last step
@@ -2459,9 +2543,14 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     const DeviceStep &d = p->dsteps[step];
     const LevelCtx cx = main_ctx(p, step);
     const int n = static_cast<int>(s.n), nd = static_cast<int>(s.n_dragged), n_new = n - nd;
-    const int none = static_cast<int>(s.n_prev);
+    // (a source cut stored by slot: "none" is row P of its matrix; kernel = 1 sweeps never store by slot)
+    const bool by_slot = s.src_slots && kernel != 1;
+    const int none = by_slot ? s.P : static_cast<int>(s.n_prev);
     const unsigned thr = cert_threshold(p->tun);
     int *cert_out = cx.cert_out;
+    const bool stay = s.stay && kernel != 1;
+    if (stay && n_new == 0) return GENPHI_OK;                   // the cut only lost members: nothing moves
+    if (stay) HIP_TRY(hipMemsetAsync(cert_out + s.p0, 0, static_cast<size_t>(s.npad) * sizeof(int), p->stream));   // the new members' words
     if (kernel == 1 || cx.identity) {
         // the per-entry kernel and the 1/2 I kernel take any cut width: all rows in one launch
         LevelCtx c2 = cx;
@@ -2483,14 +2572,14 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
                                d.pardesc, d.parents, n_par, p->psi_p, static_cast<long long>(nn.ld_prev), p->d_cert_p, thr);
         }
         hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n_par + 1)), dim3(256), 0, p->stream, p->psi_p,
-                           static_cast<long long>(nn.ld_prev), n_par);
+                           static_cast<long long>(nn.ld_prev), n_par, static_cast<long long>(nn.ld_prev));
         HIP_TRY(hipGetLastError());
         // 2. the new x new block: a FULL / SPLIT level step on Psi_P, written IN PLACE.  The sub-step's
         //    member lead + r is member nd + r of the cut, so its matrix starts (nd - lead) rows and
         //    columns into the cut's; the `lead` placeholder columns (zeros) land on columns
         //    [nd - lead, nd) of the new rows, which pass 3 overwrites.  The sub-step also writes the
         //    zero padding [n, ld) of its rows.
-        const long long shift = nd - nn.lead;
+        const long long shift = stay ? s.p0 : nd - nn.lead;     // (in place: the block sits at the new members' slots)
         LevelCtx cn;
         cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
         cn.cert_prev = p->d_cert_p;
@@ -2510,7 +2599,28 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     //   Per level of cfg4o (profiles/microbench/out/r02_ab_wide_route_per_level_cfg4o.out) B is faster from
     //   nd / n_prev ~ 0.67 downwards (the level at 0.29: 4.07 -> 3.52 ms), slower above (the widest level:
     //   24.9 -> 27.8 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 2/3.
-    bool route_b = !nn_naive && nd > 0 && n_new > 0 && s.nn[0].n_prev > 0;
+    if (stay) {
+        if (nn_naive) return fail(GENPHI_ERR_ARG, "internal: an in-place WIDE step without a row kernel for its new x new block");
+        // 3S. new x dragged: the new rows at the dragged members' columns, from the parents' rows of the same matrix
+        {
+            dim3 grid(static_cast<unsigned>(n_new), static_cast<unsigned>((nd + 2047) / 2048));
+            hipLaunchKernelGGL(rows_avg_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none, d.rowdesc + nd,
+                               d.idx, nd, out, cert_out, thr);
+            HIP_TRY(hipGetLastError());
+        }
+        // 4S. dragged x new = (new x dragged)^T, over the slot ranges that hold the dragged members (the dead slots among them
+        //     included: their rows and columns hold nothing that is read); destination runs start at the 64-aligned slot p0
+        for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) {
+            const int c_lo = s.live_ranges[h], len = s.live_ranges[h + 1] - c_lo;
+            dim3 gt(static_cast<unsigned>((len + kTT - 1) / kTT), static_cast<unsigned>((n_new + kTT - 1) / kTT));
+            hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(s.p0) * s.ld + c_lo,
+                               static_cast<long long>(s.ld), n_new, len, out + static_cast<long long>(c_lo) * s.ld, static_cast<long long>(s.ld),
+                               s.p0, 0, cert_out + c_lo, thr);
+            HIP_TRY(hipGetLastError());
+        }
+        return GENPHI_OK;
+    }
+    bool route_b = !nn_naive && nd > 0 && n_new > 0 && s.nn[0].n_prev > 0 && !by_slot;     // (route B's parent windows need ascending sources)
     if (route_b) route_b = p->tun.wide_route ? p->tun.wide_route == 'B' : (3LL * nd < 2LL * s.n_prev);
     if (route_b) {
         // 3B. the dragged rows, all n columns
@@ -2536,7 +2646,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         if (nd > 0 && rows_1 > 0) {
             dim3 grid(static_cast<unsigned>(rows_1), static_cast<unsigned>((nd + 2047) / 2048));      // 256 threads x 8 elements
             hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
-                               d.rowdesc, d.srcA, nd, out, static_cast<long long>(s.ld), cert_out, thr);
+                               d.rowdesc, d.idx, nd, out, static_cast<long long>(s.ld), cert_out, thr);
             HIP_TRY(hipGetLastError());
         }
         if (n_new > 0 && nn_naive) {
@@ -2560,7 +2670,8 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         }
     }
     // 5. padding columns and the "none" row
-    hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, p->stream, out, static_cast<long long>(s.ld), n);
+    hipLaunchKernelGGL(pad_zero_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, p->stream, out, static_cast<long long>(s.ld), n,
+                       static_cast<long long>(s.width));
     HIP_TRY(hipGetLastError());
     return GENPHI_OK;
 }
@@ -2701,6 +2812,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         return compute_f64(p, r0, r1, kernel, stats, timing);
     }
     if (p->popt.indices_only) return fail(GENPHI_ERR_ARG, "internal: an indices-only plan serves Float64-storage sweeps only");
+    p->stay_active = kernel != 1;             // the per-entry kernel sweep (kernel = 1) knows no slots: every level is written compactly
     rc = ensure_level_buffers(p);
     if (rc) return rc;
     const int n_steps = L - 1;
@@ -2848,6 +2960,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     const bool small_off = p->tun.no_small;                                      // test hook: per-level launches only
     std::vector<int> ev_after(std::max(n_steps, 1));                             // event recorded after step k (timing)
     for (int k = 0; k < static_cast<int>(ev_after.size()); ++k) ev_after[k] = k + 1;
+    const std::vector<int> &bid = p->buf_of[p->stay_active ? 0 : 1];       // level buffer of every cut
     auto enqueue = [&]() -> int {
         HIP_TRY(hipMemsetAsync(p->d_queues, 0, p->n_slots * 16 * sizeof(int), p->stream));
         HIP_TRY(hipMemsetAsync(p->d_gcnt, 0, p->n_slots * 4 * sizeof(int), p->stream));
@@ -2873,7 +2986,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             }
             for (int s = 0; s < n_steps; ++s) {
                 const LevelStep &st = pl.steps[s];
-                const float *psi = p->buf[s & 1];
+                const float *psi = p->buf[bid[s]];
                 const bool last = s == n_steps - 1;
                 // a run of >= 2 small intermediate steps goes through ONE launch (levels_small_kernel)
                 if (kernel == 0 && !small_off) {
@@ -2883,7 +2996,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         const size_t lds = (2 * kSmallPitch * kSmallPitch + 3 * kSmallMax) * sizeof(float);
                         HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));
                         hipLaunchKernelGGL(levels_small_kernel, dim3(1), dim3(1024), lds, p->stream, p->d_small + s, e - s,
-                                           psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[e & 1],
+                                           psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[bid[e]],
                                            static_cast<long long>(pl.ld[e]), p->d_cert + p->cert_off[e], cert_threshold(p->tun));
                         HIP_TRY(hipGetLastError());
                         // per-level timing: ONE event for the run, booked on its first step (an event
@@ -2897,9 +3010,13 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     }
                 }
                 if (!last) {
-                    float *out = p->buf[(s + 1) & 1];
-                    if (st.mode == genphi::kModeWide)
+                    float *out = p->buf[bid[s + 1]];
+                    if (st.mode == genphi::kModeWide) {
+                        // the first in-place step of a run: the all-zero "none" row P of the run's matrix
+                        if (p->stay_active && st.stay && !(s > 0 && pl.steps[s - 1].stay))
+                            HIP_TRY(hipMemsetAsync(out + static_cast<long long>(st.P) * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
                         rc = launch_wide_level(p, s, psi, out, kernel);
+                    }
                     else if (p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step)
                         rc = launch_level(p, main_ctx(p, s), psi, out, p->sh_steps[s].rows, nullptr, p->sh_steps[s].n_rows, kernel,
                                           p->sh_steps[s].groups);

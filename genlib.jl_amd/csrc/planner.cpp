@@ -373,6 +373,29 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         for (int64_t x = 0; x < n_ind; ++x) if (tlast[x] >= 0) new_of[L - 1 - tlast[x]].push_back(static_cast<int32_t>(x));
     }
 
+    // cut sizes (independent of any order): x is in the cuts c_new(x) = L-1-tlast .. c_last(x) = L-1-tfirst
+    std::vector<int64_t> size_of(L, 0);
+    {
+        std::vector<int64_t> diff(static_cast<size_t>(L) + 1, 0);
+        for (int64_t x = 0; x < n_ind; ++x) if (tlast[x] >= 0) { diff[L - 1 - tlast[x]]++; diff[L - tfirst[x]]--; }
+        int64_t run = 0;
+        for (int32_t c = 0; c < L; ++c) { run += diff[c]; size_of[c] = run; }
+    }
+    // Cuts produced by a WIDE step may be kept in place (LevelStep::stay): their new members are then ordered by the cut after
+    // which they leave, earliest first (rank order inside a class), so that the slots of a block die from its start.
+    const bool stay_on = !opt.indices_only && !opt.no_stay;
+    auto wide_step = [&](int32_t c) { return c >= 1 && c < L && mode_for(size_of[c - 1], opt) == kModeWide; };   // the step that produces cut c
+    if (stay_on) {
+        std::vector<int32_t> key(n_ind > 0 ? n_ind : 1, 0), tmp, cnt;
+        for (int32_t c = 1; c + 1 < L; ++c) {
+            if (!wide_step(c) || !wide_step(c + 1) || new_of[c].size() < 2) continue;
+            for (int32_t x : new_of[c]) key[x] = L - 1 - tfirst[x];      // the last cut x is in: early leavers first (the slots are
+                                                                         // a circular queue: what entered first, or sits lowest, dies first)
+            counting_sort(new_of[c], tmp, key, L, cnt);
+            new_of[c].swap(tmp);
+        }
+    }
+
     // ---- storage order of every cut: [dragged by previous position..., new by rank...];
     //      the last cut keeps the proband order (contractual) unless its step is WIDE ----------
     std::vector<std::vector<int32_t>> cut(L);
@@ -390,6 +413,100 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         plan.cut_sizes[c] = static_cast<int64_t>(cut[c].size());
         plan.ld[c] = pitch_for(plan.cut_sizes[c]);
         plan.max_cut = std::max(plan.max_cut, plan.cut_sizes[c]);
+    }
+    // ---- runs of WIDE steps whose members stay in place (see LevelStep::stay) ---------------------------------
+    // stay_c[c]: the step producing cut c writes in place; slotP[c] > 0: cut c is stored by slot, capacity slotP[c];
+    // slots_c[c][k]: slot of member k of cut c; abs?_c[c][k]: slots of the sources (in cut c - 1) of member k of cut c
+    std::vector<char> stay_c(L, 0);
+    std::vector<int32_t> slotP(L, 0), p0_c(L, 0), npad_c(L, 0);
+    std::vector<std::vector<int32_t>> slots_c(L), absA_c(L), absB_c(L);
+    if (stay_on) {
+        auto pad64 = [](int64_t v) { return (v + 63) / 64 * 64; };
+        std::vector<int32_t> slot_of(n_ind > 0 ? n_ind : 1, -1);
+        std::vector<int32_t> seen(n_ind > 0 ? n_ind : 1, -1);
+        int32_t call = 0;
+        auto n_parents = [&](int32_t c) {                            // distinct parents of the new members of cut c
+            int64_t np = 0;
+            ++call;
+            for (int32_t x : new_of[c]) {
+                if (fa[x] >= 0 && seen[fa[x]] != call) { seen[fa[x]] = call; ++np; }
+                if (mo[x] >= 0 && seen[mo[x]] != call) { seen[mo[x]] = call; ++np; }
+            }
+            return np;
+        };
+        // (the new x new block of the step itself and of the step that reads its cut must have a row kernel: the per-entry
+        // fallback knows no slots; cut 1 is out because cut 0 = 1/2 I is normally never materialised)
+        auto nn_ok = [&](int32_t c) { return new_of[c].empty() || mode_for(n_parents(c), opt) != kModeWide; };
+        auto can = [&](int32_t c) {
+            // (worth it while the dragged x dragged block that is not copied outweighs the new rows: late levels of shrinking cuts
+            // have few dragged members, and reading a cut by slot costs the next step its faster route)
+            return c >= 2 && wide_step(c) && c + 1 < L && wide_step(c + 1) && cut[c].size() >= 2 * new_of[c].size() && nn_ok(c) && nn_ok(c + 1);
+        };
+        std::vector<int32_t> last_at;                                // per slot: last cut of its occupant (-1: free)
+        for (int32_t c = 1; c + 1 < L;) {
+            if (!can(c)) { ++c; continue; }
+            int32_t e = c;
+            while (e + 2 < L && can(e + 1)) ++e;
+            int64_t P = 0, blk = 0;
+            for (int32_t cc = c; cc <= e; ++cc) {
+                P = std::max(P, size_of[cc - 1] + pad64(static_cast<int64_t>(new_of[cc].size())));
+                blk = std::max(blk, pad64(static_cast<int64_t>(new_of[cc].size())));
+            }
+            P = pad64(P + 64) + std::max(0, opt.stay_headroom) * blk;
+            if (P > opt.stay_max_slots || P >= (int64_t(1) << 30)) { c = e + 1; continue; }
+            // the entry cut c - 1 sits at slots [0, n) of the matrix (written compactly, with pitch P, by its own step)
+            const std::vector<int32_t> &ent = cut[c - 1];
+            last_at.assign(static_cast<size_t>(P), -1);
+            for (size_t k = 0; k < ent.size(); ++k) { slot_of[ent[k]] = static_cast<int32_t>(k); last_at[k] = L - 1 - tfirst[ent[k]]; }
+            slots_c[c - 1].resize(ent.size());
+            std::iota(slots_c[c - 1].begin(), slots_c[c - 1].end(), 0);
+            int64_t hi = pad64(static_cast<int64_t>(ent.size()));    // the next block starts here: the slots are a circular queue whose
+                                                                     // oldest occupants (the lowest slots of the entry cut first) die first
+            int32_t done = c - 1;                                    // last cut stored by slot
+            auto sources = [&](int32_t cc) {                         // slots of the sources of cut cc's members (cut cc - 1 is stored by slot)
+                const int32_t d = L - 1 - cc;
+                const size_t n = cut[cc].size();
+                absA_c[cc].resize(n); absB_c[cc].resize(n);
+                const int32_t none = static_cast<int32_t>(P);
+                for (size_t k = 0; k < n; ++k) {
+                    const int32_t x = cut[cc][k];
+                    if (tlast[x] > d) { absA_c[cc][k] = slot_of[x]; absB_c[cc][k] = none; continue; }
+                    const int32_t a = fa[x] >= 0 ? slot_of[fa[x]] : -1, b = mo[x] >= 0 ? slot_of[mo[x]] : -1;
+                    if (a >= 0 && b >= 0) { absA_c[cc][k] = a; absB_c[cc][k] = b; }
+                    else if (a >= 0) { absA_c[cc][k] = a; absB_c[cc][k] = none; }
+                    else if (b >= 0) { absA_c[cc][k] = b; absB_c[cc][k] = none; }
+                    else { absA_c[cc][k] = absB_c[cc][k] = none; }
+                }
+            };
+            for (int32_t cc = c; cc <= e; ++cc) {
+                const int64_t n_new = static_cast<int64_t>(new_of[cc].size()), npad = pad64(n_new);
+                int64_t start = hi;
+                if (start + npad > P) start = 0;                     // wrap: the few slots left at the top stay unused
+                bool ok = true;
+                for (int64_t q = start; q < start + npad && ok; ++q) ok = last_at[q] < cc - 1;      // gone before the source cut
+                if (!ok) break;
+                sources(cc);                                         // (before the new members get their slots)
+                const size_t n = cut[cc].size(), nd = n - static_cast<size_t>(n_new);
+                slots_c[cc].resize(n);
+                for (size_t k = 0; k < nd; ++k) slots_c[cc][k] = slot_of[cut[cc][k]];
+                for (int64_t q = start; q < start + npad; ++q) last_at[q] = -1;
+                for (size_t k = nd; k < n; ++k) {
+                    const int32_t x = cut[cc][k], q = static_cast<int32_t>(start + static_cast<int64_t>(k - nd));
+                    slot_of[x] = q; slots_c[cc][k] = q; last_at[q] = L - 1 - tfirst[x];
+                }
+                stay_c[cc] = 1; p0_c[cc] = static_cast<int32_t>(start); npad_c[cc] = static_cast<int32_t>(npad);
+                if (n_new > 0) hi = start + npad;
+                done = cc;
+            }
+            if (done >= c) {
+                for (int32_t cc = c - 1; cc <= done; ++cc) { slotP[cc] = static_cast<int32_t>(P); plan.ld[cc] = P; }
+                sources(done + 1);                                   // the step that leaves the run reads by slot
+                c = done + 2;
+            } else {
+                slots_c[c - 1].clear();
+                ++c;
+            }
+        }
     }
     const bool last_wide = L >= 2 && mode_for(plan.cut_sizes[L - 2], opt) == kModeWide;
     if (!last_wide) {
@@ -431,7 +548,9 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         const int64_t n = plan.cut_sizes[c], n_prev = plan.cut_sizes[c - 1];
         const int32_t d = L - 1 - c;
         st.n_prev = n_prev; st.n = n;
-        st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c]; st.width = st.ld;
+        st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
+        // (the entry cut of an in-place run has the run's pitch P but is written compactly: no zero padding beyond its own width)
+        st.width = (slotP[c] > 0 && !stay_c[c]) ? pitch_for(n) : st.ld;
         st.mode = mode_for(n_prev, opt);
         st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
         const int32_t none = static_cast<int32_t>(n_prev);
@@ -452,6 +571,24 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         plan.both_counts[c - 1] = dragged;
         if (opt.indices_only) return;
         if (st.mode != kModeWide) { finish_narrow_step(st, w); return; }
+        if (slotP[c - 1] > 0) {                                        // the source cut is stored by slot
+            st.src_slots = true; st.P = slotP[c - 1];
+            st.absA = std::move(absA_c[c]); st.absB = std::move(absB_c[c]);
+        }
+        if (stay_c[c]) {
+            st.stay = true; st.p0 = p0_c[c]; st.npad = npad_c[c]; st.out_slots = slots_c[c];
+            // slot ranges that hold the dragged members (gaps of up to 255 dead slots are bridged): what the new columns are written to
+            std::vector<int32_t> ds(st.out_slots.begin(), st.out_slots.begin() + dragged);
+            std::sort(ds.begin(), ds.end());
+            for (size_t k = 0; k < ds.size();) {
+                size_t e = k;
+                while (e + 1 < ds.size() && ds[e + 1] - ds[e] <= 256) ++e;
+                const int32_t lo = ds[k] / 64 * 64, hi = std::min<int32_t>((ds[e] + 64) / 64 * 64, st.P);     // 64-aligned: 256-byte destination runs
+                if (!st.live_ranges.empty() && lo <= st.live_ranges.back()) st.live_ranges.back() = std::max(st.live_ranges.back(), hi);
+                else { st.live_ranges.push_back(lo); st.live_ranges.push_back(hi); }
+                k = e + 1;
+            }
+        }
 
         // WIDE: the cut is [dragged..., new...]; the new x new block becomes a step of its own
         // over the compacted parent x parent matrix Psi[parents][parents]
@@ -465,6 +602,10 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         for (int64_t q = 0; q < n_prev; ++q)
             if (is_par[q]) { pidx[q] = static_cast<int32_t>(st.parents.size()); st.parents.push_back(static_cast<int32_t>(q)); }
         const int64_t n_par = static_cast<int64_t>(st.parents.size());
+        if (st.src_slots) {
+            st.parents_abs.resize(n_par);
+            for (int64_t u = 0; u < n_par; ++u) st.parents_abs[u] = slots_c[c - 1][st.parents[u]];
+        }
         const int nn_mode = mode_for(n_par, opt);
         if (nn_mode == kModeWide) { st.nn_naive = true; return; }
         st.nn.resize(1);
@@ -472,10 +613,12 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         // written in place (rows / columns [dragged, n) of this cut's matrix): `lead` placeholder
         // members in front put the block's first column on a 16-byte boundary of the rows (128-byte
         // alignment measured no faster: profiles/microbench/out/r02_ab_nn_block_alignment_cfg4o.out)
-        const int64_t lead = dragged % 4;
+        // (a step that stays in place writes the block at the 64-aligned slots [p0, p0 + n_new): no placeholders, and its rows
+        // write no further than the block's npad slots)
+        const int64_t lead = st.stay ? 0 : dragged % 4;
         nn.lead = static_cast<int32_t>(lead);
         nn.n_prev = n_par; nn.n = lead + n_new;
-        nn.ld_prev = pitch_for(n_par); nn.ld = st.ld; nn.width = st.ld - (dragged - lead);
+        nn.ld_prev = pitch_for(n_par); nn.ld = st.ld; nn.width = st.stay ? st.npad : st.width - (dragged - lead);
         nn.mode = nn_mode;
         nn.srcA.resize(nn.n); nn.srcB.resize(nn.n); nn.ord.resize(nn.n);
         const int32_t pnone = static_cast<int32_t>(n_par);

@@ -65,6 +65,20 @@ struct LevelStep {
     std::vector<LevelStep> nn;
     int32_t lead = 0;                 // (of a sub-step) placeholder members in front
     bool nn_naive = false;
+    // WIDE, members that STAY where they are (persistent slots; Float32 sweep only -- everything above keeps its compact meaning
+    // for the other sweeps).  A run of consecutive WIDE steps can keep ONE level matrix of pitch / capacity P in place: a member
+    // owns the same row and column (its SLOT, an absolute position in [0, P)) for as long as it is in the cuts, so the
+    // dragged x dragged block -- most of a level of overlapping generations -- is never copied.  New members take a contiguous,
+    // 64-aligned block of slots above the previous block (circularly), over members that left the cuts at least one step earlier;
+    // within a block they are ordered by the step at which they leave (earliest first): the slots are a circular queue that dies from its old end.
+    //   src_slots   the source cut is stored by slot: absA / absB = the sources' slots (P = none), parents_abs likewise
+    //   stay        the output cut is stored by slot, in the SAME matrix: only the new rows / columns are written, at
+    //               [p0, p0 + n_new) (npad >= n_new slots reserved: the rows' ragged last quad may spill into the padding)
+    //   out_slots   slot of every member of the output cut (stay steps)
+    bool src_slots = false, stay = false;
+    int32_t P = 0, p0 = 0, npad = 0;
+    std::vector<int32_t> absA, absB, parents_abs, out_slots;
+    std::vector<int32_t> live_ranges;      // (stay) [lo, hi) slot ranges, 64-aligned, ascending, that hold the dragged members
 };
 
 struct Plan {
@@ -88,6 +102,10 @@ struct PlanOptions {
     int32_t lds_cap_floats = 36864;   // floats of LDS a workgroup may use for staged source rows (9 * 1024 float4; 160 KB minus the work-queue slots)
     bool indices_only = false;        // cuts and per-member sources / rank words only (every step marked FULL, no pk words, no
                                       // work order, the last cut in proband order): what the column-panel multi-GPU path needs
+    bool no_stay = false;             // never keep WIDE levels in place (A/B and test hook)
+    int64_t stay_max_slots = 200000;  // largest slot capacity P of a run (a P x P Float32 matrix: 160 GB)
+    int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):
+                                      // more of them = longer runs before the slot space is full (memory: P grows)
 };
 
 // Returns 0 or a GENPHI_ERR_* code (see include/genphi.h); message in err.

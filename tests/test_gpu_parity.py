@@ -750,6 +750,56 @@ def test_wide_levels_block_assembly(gen, oracle, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
+@pytest.mark.gpu
+def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
+    """Persistent slots (csrc/planner.h LevelStep::stay): in a run of WIDE steps the members keep their row / column of ONE
+    level matrix, the dragged x dragged block (src/compute.jl:108-110) is never copied, new members take the slots of members
+    that left the cuts.  Forced here by a small LDS budget on overlapping-generation pedigrees: growing and shrinking cuts, runs
+    that wrap around the slot space, the step that leaves a run (reads by slot, writes compactly), certificates on and off
+    (the grouping-exact kernels), repeated sweeps on one plan (dead slots keep stale values), the captured-graph replay, the
+    per-entry kernel sweep on the same plan (no slots), row shards; == the oracle, and == the same plan without in-place steps."""
+    from genlib_jl_amd import synth
+    stays = 0
+    # (cuts wider than the LDS budget whose new members' parents fit in it: the new x new block has a row kernel)
+    for cap, args, kw in [(3000, (20000, 300, 18), dict(skip_permille=500, seed=2)),
+                          (2000, (30000, 400, 30), dict(skip_permille=600, seed=3)),
+                          (1200, (12000, 500, 24), dict(skip_permille=700, seed=8)),
+                          (900, (8000, 300, 20), dict(skip_permille=800, seed=21))]:
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        for env in ({}, {"GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_STAY_HEADROOM": "3"},
+                    {"GENPHI_STAY_HEADROOM": "2", "GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_NO_STAY": "1"}):
+            for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM"):
+                monkeypatch.delenv(k, raising=False)
+            monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pl = gen.plan(ped, pro)
+            n_steps = len(pl.step_modes())
+            flags = [pl.step_slots(k) for k in range(n_steps)]
+            n_stay = sum(f[0] & 1 for f in flags)
+            if "GENPHI_NO_STAY" in env:
+                assert n_stay == 0 and all(f == (0, 0, 0, 0) for f in flags)
+            else:
+                assert n_stay >= 2, flags
+                stays += n_stay
+                for k, f in enumerate(flags):
+                    if f[0] & 1:                     # in place: reads and writes by slot, the next step reads by slot too
+                        assert f[0] & 2 and flags[k + 1][0] & 2 and f[2] % 64 == 0 and f[3] % 64 == 0 and f[2] + f[3] <= f[1]
+            for rep in range(4):                     # (the 3rd and 4th call of a >= 8-step sweep replay the captured graph)
+                _assert_equal(pl.compute(), want)
+            _assert_equal(pl.compute(kernel=1), want)
+            _assert_equal(pl.compute(), want)
+            n = len(want)
+            parts = [pl.compute(rows=r) for r in [(0, 5), (5, n // 3), (n // 3, n)]]
+            _assert_equal(np.concatenate(parts, axis=0), want)
+            pl.close()
+    assert stays >= 100
+    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_pairwise_phi_float64(gen, oracle):
     """gen.phi(individual_i, individual_j) (src/compute.jl:66-95): Float64 kinship of a pair from one
     Float64 level sweep.  Reference pins: test/runtests.jl:49 (phi(ped[1], ped[2]) == 0.37109375) and
