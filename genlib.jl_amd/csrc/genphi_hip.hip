@@ -1204,6 +1204,63 @@ transpose_block_kernel(const float *__restrict__ src, long long ld_src, int rows
     }
 }
 
+// In-place WIDE steps: new member r of the step sits at slot blk_slot[r / 64] + r % 64 (granules of 64 free slots).
+// The new x new block, computed into a compact n_new x n_new buffer t (pitch ld_t) by the FULL / SPLIT sub-step, goes to the
+// members' rows and columns of the level matrix; the rows' certificate words travel with them.  One workgroup per row.
+__global__ void __launch_bounds__(256)
+slots_scatter_kernel(const float *__restrict__ t, long long ld_t, int n_new, const int *__restrict__ blk_slot, float *__restrict__ m,
+                     long long ld, const int *__restrict__ cert_t, int *__restrict__ cert_out)
+{
+    const int r = blockIdx.x;
+    const int row = blk_slot[r >> 6] + (r & 63);
+    const float4 *src = reinterpret_cast<const float4 *>(t + (long long)r * ld_t);
+    float *dst = m + (long long)row * ld;
+    const int n4 = (n_new + 3) / 4;                               // (the last quad may spill into the granule's padding slots)
+    for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
+        const int c = c4 * 4;
+        *reinterpret_cast<float4 *>(dst + blk_slot[c >> 6] + (c & 63)) = src[c4];
+    }
+    if (threadIdx.x == 0 && cert_out) cert_out[row] = cert_t[r];
+}
+// certificate words of the new members' slots := 0 (before the step flags them)
+__global__ void __launch_bounds__(256) slots_clear_kernel(int *__restrict__ words, const int *__restrict__ blk_slot, int n_gran)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n_gran * 64) words[blk_slot[k >> 6] + (k & 63)] = 0;
+}
+// dragged x new = (new x dragged)^T in place: source row r of the block = new member r (row slot(r) of m), destination
+// column slot(r), for the columns / destination rows [c_lo, c_lo + cols).  64 x 64 tiles: a tile row is one granule.
+__global__ void __launch_bounds__(256)
+transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict__ blk_slot, int c_lo, int cols, int *__restrict__ cert_out,
+                       unsigned cert_thresh)
+{
+    __shared__ float tile[kTT][kTT + 1];
+    const int g = blockIdx.y, c0 = c_lo + blockIdx.x * kTT;
+    const int base = blk_slot[g];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int rows_here = min(64, n_new - g * 64);
+    for (int kb = ty; kb < kTT; kb += 32) {                      // 8 loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rl = min(kb + 4 * u, rows_here - 1), c = min(c0 + tx, c_lo + cols - 1);       // clamped: unconditional loads
+            v[u] = m[(long long)(base + rl) * ld + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tile[kb + 4 * u][tx] = v[u];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = ty; k < kTT; k += 4) {
+        const int c = c0 + k;
+        if (c < c_lo + cols && tx < rows_here) {
+            const float v = tile[tx][k];
+            m[(long long)c * ld + base + tx] = v;
+            if (cert_out && cert_key(v) < cert_thresh) cert_out[c] = 1;
+        }
+    }
+}
+
 // zero padding of a level matrix: columns [n, ld) of rows 0..n-1 and the whole "none" row n
 // (width <= ld: the columns the level owns -- the entry cut of an in-place run has the run's pitch, but only its own width is padded)
 __global__ void __launch_bounds__(256) pad_zero_kernel(float *__restrict__ m, long long ld, int n, long long width)
@@ -1463,7 +1520,7 @@ __global__ void __launch_bounds__(256) level_identity_kernel(const LevelArgs p)
     const int none = p.n_prev;
     auto h = [none](int x, int y) -> float { return (x == y && x != none) ? 0.5f : 0.f; };
     float *orowp = p.out + orow * p.ld;
-    for (long long jq = (long long)threadIdx.x * 4; jq < p.ld; jq += 4 * blockDim.x) {
+    for (long long jq = (long long)threadIdx.x * 4; jq < p.width; jq += 4 * blockDim.x) {
         // an entry is non-zero only where row and column share a source (or on the diagonal):
         // rare, so most waves take the all-zero path and the kernel runs at the speed of its stores
         int Aj[4], Bj[4];
@@ -1710,6 +1767,7 @@ struct DeviceStep {
     int *pstart = nullptr;     // drag_rows_kernel: first parent of each chunk of 8192 dragged columns
     int *idx = nullptr;        // source column of every dragged member (= srcA; the sources' SLOTS when the source cut is stored by slot:
                                // then rowdesc / pardesc / parents hold slots too, see LevelStep::src_slots)
+    int *blk_slot = nullptr;   // (in-place steps) first slot of every granule of 64 new members
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -1752,6 +1810,8 @@ struct genphi_plan {
     std::vector<const LevelStep *> nn_steps;     // new x new sub-steps of the WIDE steps (owned by the plan's steps)
     std::vector<DeviceStep> nn_dsteps;
     float *psi_p = nullptr;                      // WIDE: compacted parent matrix Psi[parents][parents]
+    float *nn_tmp = nullptr;                     // in-place WIDE steps: the new x new block before it is scattered to the new members' slots
+    int *d_cert_t = nullptr;                     // ... and its rows' certificate words
     int *d_cert_p = nullptr;                     // certificates of the rows of psi_p
     size_t cert_p_words = 0;
     int *d_final_perm = nullptr;
@@ -1835,7 +1895,7 @@ static void free_device(genphi_plan *p)
     p->shard_groups = DeviceGroups(); p->shard_blob_bytes = 0; p->cert_off.clear(); p->cert_words = 0;
     release(p->d_queues); release(p->d_small); release(p->sh_blob); release(p->scratch);
     release(p->buf[0]); release(p->buf[1]); release(p->result); release(p->final_tmp);
-    release(p->psi_p); release(p->d_cert_p);
+    release(p->psi_p); release(p->d_cert_p); release(p->nn_tmp); release(p->d_cert_t);
     release(p->buf64[0]); release(p->buf64[1]); release(p->result64); release(p->d_perm_rows);
     p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
     p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
@@ -2014,7 +2074,8 @@ static int upload_plan_impl(genphi_plan *p, int device)
         }
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
-                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int));
+                     al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +
+                     al(s.blk_slot.size() * sizeof(int));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
@@ -2060,6 +2121,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
             d.parents = reinterpret_cast<int *>(put(par, s.parents.size() * sizeof(int)));
             d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
             d.idx = reinterpret_cast<int *>(put(sA, s.n_dragged * sizeof(int)));
+            d.blk_slot = reinterpret_cast<int *>(put(s.blk_slot.data(), s.blk_slot.size() * sizeof(int)));
             // drag_rows_kernel: parents inside the source window of each chunk of 8192 dragged columns
             const int64_t chunk = 8192, nch = (s.n_dragged + chunk - 1) / chunk;
             std::vector<int> ps(nch + 1, 0);
@@ -2141,6 +2203,14 @@ static int ensure_level_buffers_impl(genphi_plan *p)
         for (const LevelStep *nn : p->nn_steps) {
             need_p = std::max(need_p, static_cast<size_t>((nn->n_prev + 1) * nn->ld_prev) + kTailPadFloats);
             need_c = std::max(need_c, static_cast<size_t>(nn->n_prev) + 1);
+        }
+        size_t need_t = 0;                                         // in-place steps: npad x npad block + its certificate words
+        for (const LevelStep &st : pl.steps)
+            if (st.stay) need_t = std::max(need_t, static_cast<size_t>(st.npad));
+        if (need_t) {
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->nn_tmp), (need_t * need_t + kTailPadFloats) * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(p->nn_tmp, 0, (need_t * need_t + kTailPadFloats) * sizeof(float), p->stream));
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_t), (need_t + 1) * sizeof(int)));
         }
         if (need_p) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
@@ -2549,8 +2619,6 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     const unsigned thr = cert_threshold(p->tun);
     int *cert_out = cx.cert_out;
     const bool stay = s.stay && kernel != 1;
-    if (stay && n_new == 0) return GENPHI_OK;                   // the cut only lost members: nothing moves
-    if (stay) HIP_TRY(hipMemsetAsync(cert_out + s.p0, 0, static_cast<size_t>(s.npad) * sizeof(int), p->stream));   // the new members' words
     if (kernel == 1 || cx.identity) {
         // the per-entry kernel and the 1/2 I kernel take any cut width: all rows in one launch
         LevelCtx c2 = cx;
@@ -2558,6 +2626,12 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         if (rc) return rc;
         if (kernel == 1) HIP_TRY(hipMemsetAsync(out + s.n * s.ld, 0, static_cast<size_t>(s.ld) * sizeof(float), p->stream));
         return GENPHI_OK;
+    }
+    if (stay && n_new == 0) return GENPHI_OK;                   // the cut only lost members: nothing moves
+    const int n_gran = static_cast<int>(s.blk_slot.size());
+    if (stay) {                                                 // the new members' certificate words
+        hipLaunchKernelGGL(slots_clear_kernel, dim3(static_cast<unsigned>((n_gran * 64 + 255) / 256)), dim3(256), 0, p->stream, cert_out, d.blk_slot, n_gran);
+        HIP_TRY(hipMemsetAsync(p->d_cert_t, 0, (static_cast<size_t>(s.npad) + 1) * sizeof(int), p->stream));
     }
     const bool nn_naive = s.nn_naive || s.nn.empty();
     if (n_new > 0 && !nn_naive) {
@@ -2579,14 +2653,21 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         //    columns into the cut's; the `lead` placeholder columns (zeros) land on columns
         //    [nd - lead, nd) of the new rows, which pass 3 overwrites.  The sub-step also writes the
         //    zero padding [n, ld) of its rows.
-        const long long shift = stay ? s.p0 : nd - nn.lead;     // (in place: the block sits at the new members' slots)
+        const long long shift = nd - nn.lead;
         LevelCtx cn;
         cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
         cn.cert_prev = p->d_cert_p;
-        cn.cert_out = cert_out + shift;
+        cn.cert_out = stay ? p->d_cert_t : cert_out + shift;
         cn.identity = false; cn.dbg = false; cn.no_none_row = true;
-        const int rc = launch_level(p, cn, p->psi_p, out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
+        // (in place: the block goes to a compact buffer of its own -- the sub-step's pitch is npad -- and from there to the new
+        // members' rows and columns)
+        const int rc = launch_level(p, cn, p->psi_p, stay ? p->nn_tmp : out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
         if (rc) return rc;
+        if (stay) {
+            hipLaunchKernelGGL(slots_scatter_kernel, dim3(static_cast<unsigned>(n_new)), dim3(256), 0, p->stream, p->nn_tmp, static_cast<long long>(nn.ld),
+                               n_new, d.blk_slot, out, static_cast<long long>(s.ld), p->d_cert_t, cert_out);
+            HIP_TRY(hipGetLastError());
+        }
     }
     // Two routes for the blocks that involve dragged members:
     //   A  rows_compact_kernel on every row (dragged x dragged, new x dragged), then dragged x new as the
@@ -2609,13 +2690,12 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
             HIP_TRY(hipGetLastError());
         }
         // 4S. dragged x new = (new x dragged)^T, over the slot ranges that hold the dragged members (the dead slots among them
-        //     included: their rows and columns hold nothing that is read); destination runs start at the 64-aligned slot p0
+        //     included: their rows and columns hold nothing that is read); a tile row is one granule of new members
         for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) {
             const int c_lo = s.live_ranges[h], len = s.live_ranges[h + 1] - c_lo;
-            dim3 gt(static_cast<unsigned>((len + kTT - 1) / kTT), static_cast<unsigned>((n_new + kTT - 1) / kTT));
-            hipLaunchKernelGGL(transpose_block_kernel, gt, dim3(256), 0, p->stream, out + static_cast<long long>(s.p0) * s.ld + c_lo,
-                               static_cast<long long>(s.ld), n_new, len, out + static_cast<long long>(c_lo) * s.ld, static_cast<long long>(s.ld),
-                               s.p0, 0, cert_out + c_lo, thr);
+            dim3 gt(static_cast<unsigned>((len + kTT - 1) / kTT), static_cast<unsigned>(n_gran));
+            hipLaunchKernelGGL(transpose_slots_kernel, gt, dim3(256), 0, p->stream, out, static_cast<long long>(s.ld), n_new, d.blk_slot, c_lo, len,
+                               cert_out, thr);
             HIP_TRY(hipGetLastError());
         }
         return GENPHI_OK;

@@ -387,8 +387,11 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     auto wide_step = [&](int32_t c) { return c >= 1 && c < L && mode_for(size_of[c - 1], opt) == kModeWide; };   // the step that produces cut c
     if (stay_on) {
         std::vector<int32_t> key(n_ind > 0 ? n_ind : 1, 0), tmp, cnt;
-        for (int32_t c = 1; c + 1 < L; ++c) {
-            if (!wide_step(c) || !wide_step(c + 1) || new_of[c].size() < 2) continue;
+        bool any_run = false;                                            // two WIDE steps in a row somewhere?
+        for (int32_t c = 2; c + 1 < L && !any_run; ++c) any_run = wide_step(c) && wide_step(c + 1);
+        // (every block of such a plan, the cuts above the WIDE region too: the cut a run starts from is made of them)
+        for (int32_t c = 0; c + 1 < L && any_run; ++c) {
+            if (new_of[c].size() < 2) continue;
             for (int32_t x : new_of[c]) key[x] = L - 1 - tfirst[x];      // the last cut x is in: early leavers first (the slots are
                                                                          // a circular queue: what entered first, or sits lowest, dies first)
             counting_sort(new_of[c], tmp, key, L, cnt);
@@ -418,8 +421,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     // stay_c[c]: the step producing cut c writes in place; slotP[c] > 0: cut c is stored by slot, capacity slotP[c];
     // slots_c[c][k]: slot of member k of cut c; abs?_c[c][k]: slots of the sources (in cut c - 1) of member k of cut c
     std::vector<char> stay_c(L, 0);
-    std::vector<int32_t> slotP(L, 0), p0_c(L, 0), npad_c(L, 0);
-    std::vector<std::vector<int32_t>> slots_c(L), absA_c(L), absB_c(L);
+    std::vector<int32_t> slotP(L, 0), npad_c(L, 0);
+    std::vector<std::vector<int32_t>> slots_c(L), absA_c(L), absB_c(L), gran_c(L);
     if (stay_on) {
         auto pad64 = [](int64_t v) { return (v + 63) / 64 * 64; };
         std::vector<int32_t> slot_of(n_ind > 0 ? n_ind : 1, -1);
@@ -452,7 +455,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                 P = std::max(P, size_of[cc - 1] + pad64(static_cast<int64_t>(new_of[cc].size())));
                 blk = std::max(blk, pad64(static_cast<int64_t>(new_of[cc].size())));
             }
-            P = pad64(P + 64) + std::max(0, opt.stay_headroom) * blk;
+            P = pad64(P + P / 16 + 64) + std::max(0, opt.stay_headroom) * blk;      // ~6 % of slack for granules that are only partly dead
             if (P > opt.stay_max_slots || P >= (int64_t(1) << 30)) { c = e + 1; continue; }
             // the entry cut c - 1 sits at slots [0, n) of the matrix (written compactly, with pitch P, by its own step)
             const std::vector<int32_t> &ent = cut[c - 1];
@@ -460,8 +463,11 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             for (size_t k = 0; k < ent.size(); ++k) { slot_of[ent[k]] = static_cast<int32_t>(k); last_at[k] = L - 1 - tfirst[ent[k]]; }
             slots_c[c - 1].resize(ent.size());
             std::iota(slots_c[c - 1].begin(), slots_c[c - 1].end(), 0);
-            int64_t hi = pad64(static_cast<int64_t>(ent.size()));    // the next block starts here: the slots are a circular queue whose
-                                                                     // oldest occupants (the lowest slots of the entry cut first) die first
+            // New members are placed 64 slots (a GRANULE) at a time: a granule is free when everything in it left the cuts before
+            // the step's source cut.  The search goes round the slot space from where the last one ended, so the new members of a
+            // step mostly sit in a few long stretches (what died together was born together: blocks are ordered by leaving time).
+            const int64_t n_gran = P / 64;
+            int64_t gpos = pad64(static_cast<int64_t>(ent.size())) / 64;
             int32_t done = c - 1;                                    // last cut stored by slot
             auto sources = [&](int32_t cc) {                         // slots of the sources of cut cc's members (cut cc - 1 is stored by slot)
                 const int32_t d = L - 1 - cc;
@@ -478,24 +484,28 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                     else { absA_c[cc][k] = absB_c[cc][k] = none; }
                 }
             };
+            std::vector<int32_t> got;
             for (int32_t cc = c; cc <= e; ++cc) {
-                const int64_t n_new = static_cast<int64_t>(new_of[cc].size()), npad = pad64(n_new);
-                int64_t start = hi;
-                if (start + npad > P) start = 0;                     // wrap: the few slots left at the top stay unused
-                bool ok = true;
-                for (int64_t q = start; q < start + npad && ok; ++q) ok = last_at[q] < cc - 1;      // gone before the source cut
-                if (!ok) break;
+                const int64_t n_new = static_cast<int64_t>(new_of[cc].size()), need = (n_new + 63) / 64;
+                got.clear();
+                int64_t g = gpos;
+                for (int64_t scanned = 0; scanned < n_gran && static_cast<int64_t>(got.size()) < need; ++scanned, g = (g + 1) % n_gran) {
+                    bool free_g = true;
+                    for (int64_t q = 64 * g; q < 64 * g + 64 && free_g; ++q) free_g = last_at[q] < cc - 1;      // gone before the source cut
+                    if (free_g) got.push_back(static_cast<int32_t>(64 * g));
+                }
+                if (static_cast<int64_t>(got.size()) < need) break;  // the slot space is full: this step copies the cut out (and may start a new run)
+                gpos = g;
                 sources(cc);                                         // (before the new members get their slots)
                 const size_t n = cut[cc].size(), nd = n - static_cast<size_t>(n_new);
                 slots_c[cc].resize(n);
                 for (size_t k = 0; k < nd; ++k) slots_c[cc][k] = slot_of[cut[cc][k]];
-                for (int64_t q = start; q < start + npad; ++q) last_at[q] = -1;
+                for (int32_t base : got) for (int32_t q = base; q < base + 64; ++q) last_at[q] = -1;
                 for (size_t k = nd; k < n; ++k) {
-                    const int32_t x = cut[cc][k], q = static_cast<int32_t>(start + static_cast<int64_t>(k - nd));
+                    const int32_t x = cut[cc][k], q = got[(k - nd) / 64] + static_cast<int32_t>((k - nd) % 64);
                     slot_of[x] = q; slots_c[cc][k] = q; last_at[q] = L - 1 - tfirst[x];
                 }
-                stay_c[cc] = 1; p0_c[cc] = static_cast<int32_t>(start); npad_c[cc] = static_cast<int32_t>(npad);
-                if (n_new > 0) hi = start + npad;
+                stay_c[cc] = 1; gran_c[cc] = got; npad_c[cc] = static_cast<int32_t>(64 * need);
                 done = cc;
             }
             if (done >= c) {
@@ -576,7 +586,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             st.absA = std::move(absA_c[c]); st.absB = std::move(absB_c[c]);
         }
         if (stay_c[c]) {
-            st.stay = true; st.p0 = p0_c[c]; st.npad = npad_c[c]; st.out_slots = slots_c[c];
+            st.stay = true; st.npad = npad_c[c]; st.out_slots = slots_c[c]; st.blk_slot = gran_c[c];
+            st.p0 = st.blk_slot.empty() ? 0 : st.blk_slot[0];
             // slot ranges that hold the dragged members (gaps of up to 255 dead slots are bridged): what the new columns are written to
             std::vector<int32_t> ds(st.out_slots.begin(), st.out_slots.begin() + dragged);
             std::sort(ds.begin(), ds.end());
@@ -613,12 +624,12 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         // written in place (rows / columns [dragged, n) of this cut's matrix): `lead` placeholder
         // members in front put the block's first column on a 16-byte boundary of the rows (128-byte
         // alignment measured no faster: profiles/microbench/out/r02_ab_nn_block_alignment_cfg4o.out)
-        // (a step that stays in place writes the block at the 64-aligned slots [p0, p0 + n_new): no placeholders, and its rows
-        // write no further than the block's npad slots)
+        // (a step that stays in place: no placeholders, rows of npad columns ...
         const int64_t lead = st.stay ? 0 : dragged % 4;
         nn.lead = static_cast<int32_t>(lead);
         nn.n_prev = n_par; nn.n = lead + n_new;
-        nn.ld_prev = pitch_for(n_par); nn.ld = st.ld; nn.width = st.stay ? st.npad : st.width - (dragged - lead);
+        // (... and writes the block into a buffer of its own, pitch npad, that is scattered to the new members' slots afterwards)
+        nn.ld_prev = pitch_for(n_par); nn.ld = st.stay ? st.npad : st.ld; nn.width = st.stay ? st.npad : st.width - (dragged - lead);
         nn.mode = nn_mode;
         nn.srcA.resize(nn.n); nn.srcB.resize(nn.n); nn.ord.resize(nn.n);
         const int32_t pnone = static_cast<int32_t>(n_par);

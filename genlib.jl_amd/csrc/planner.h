@@ -68,16 +68,17 @@ struct LevelStep {
     // WIDE, members that STAY where they are (persistent slots; Float32 sweep only -- everything above keeps its compact meaning
     // for the other sweeps).  A run of consecutive WIDE steps can keep ONE level matrix of pitch / capacity P in place: a member
     // owns the same row and column (its SLOT, an absolute position in [0, P)) for as long as it is in the cuts, so the
-    // dragged x dragged block -- most of a level of overlapping generations -- is never copied.  New members take a contiguous,
-    // 64-aligned block of slots above the previous block (circularly), over members that left the cuts at least one step earlier;
-    // within a block they are ordered by the step at which they leave (earliest first): the slots are a circular queue that dies from its old end.
+    // dragged x dragged block -- most of a level of overlapping generations -- is never copied.  New members take free GRANULES
+    // of 64 slots (everything in them left the cuts at least one step earlier), in the order of their block: new member r sits
+    // at blk_slot[r / 64] + r % 64.  Inside a block members are ordered by the step at which they leave (earliest first), so
+    // that what is born together and dies together frees whole granules.
     //   src_slots   the source cut is stored by slot: absA / absB = the sources' slots (P = none), parents_abs likewise
-    //   stay        the output cut is stored by slot, in the SAME matrix: only the new rows / columns are written, at
-    //               [p0, p0 + n_new) (npad >= n_new slots reserved: the rows' ragged last quad may spill into the padding)
+    //   stay        the output cut is stored by slot, in the SAME matrix: only the new rows / columns are written (npad =
+    //               64 * granules >= n_new slots reserved; p0 = the first granule, diagnostic)
     //   out_slots   slot of every member of the output cut (stay steps)
     bool src_slots = false, stay = false;
     int32_t P = 0, p0 = 0, npad = 0;
-    std::vector<int32_t> absA, absB, parents_abs, out_slots;
+    std::vector<int32_t> absA, absB, parents_abs, out_slots, blk_slot;
     std::vector<int32_t> live_ranges;      // (stay) [lo, hi) slot ranges, 64-aligned, ascending, that hold the dragged members
 };
 
