@@ -486,7 +486,9 @@ def main():
                        "pairs_per_s_kernel_only": n * n / (kernel_ms / K * 1e-3) if kernel_ms > 0 else None,
                        "unordered_pairs_per_s": (n * (n + 1) // 2) / (wall / K),      # N(N+1)/2 entries
                        "level_ms": [round(float(x), 4) for x in lvl] if len(lvl) <= 64 else None,
-                       "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None},
+                       "kernel_modes": pl.step_modes() if len(sizes) <= 65 else None,
+                       # WIDE level steps that write their cut in place (persistent slots: only new rows / columns move)
+                       "in_place_steps": sum(pl.step_slots(k)[0] & 1 for k in range(max(len(sizes) - 1, 0)))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # context, not the headline: what this access pattern (whole 96 KB rows, 16-byte
@@ -497,6 +499,9 @@ def main():
                                             + ("; STALE: collected with other kernel sources than this run's" if traffic_stale else "; same kernel sources as this run") + ")") if traffic else None,
                          "traffic_stale": traffic_stale,
                          "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
+                         # the measured bytes against the peak: BELOW `frac` when levels stay in place (the dragged x dragged
+                         # block counts in the algorithmic bytes but is never moved), above it when rows are re-read
+                         "real_traffic_frac": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "largest_level": ({"step": int(np.argmax(byt)), "GB": max(byt) / 1e9, "ms": float(lvl_kernel[int(np.argmax(byt))]),
                                             "frac": max(byt) / (float(lvl_kernel[int(np.argmax(byt))]) * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -1683,6 +1683,7 @@ struct Tuning {
     bool no_stay = false;          // GENPHI_NO_STAY          A/B + test: WIDE levels never stay in place (every level is copied into the other buffer)
     int stay_max_slots = 0;        // GENPHI_STAY_MAX_SLOTS   test: largest slot capacity of an in-place run (default: planner.h)
     int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
+    int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
                                    //                         larger: the walk chains from hub to hub (16-20 % fewer staged rows, measured no faster:
@@ -1716,6 +1717,7 @@ static Tuning tuning_from_env()
     t.no_stay = geti("GENPHI_NO_STAY", 0) != 0;
     t.stay_max_slots = geti("GENPHI_STAY_MAX_SLOTS", 0);
     t.stay_headroom = geti("GENPHI_STAY_HEADROOM", -1);
+    t.stay_mem_pct = geti("GENPHI_STAY_MEM_PCT", 0);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -1936,6 +1938,7 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     p->popt.no_stay = p->tun.no_stay;
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
+    if (p->tun.stay_mem_pct > 0) p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0;
     std::string err;
     int rc;
     try {
@@ -3071,7 +3074,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 // a run of >= 2 small intermediate steps goes through ONE launch (levels_small_kernel)
                 if (kernel == 0 && !small_off) {
                     int e = s;
-                    while (e < n_steps - 1 && pl.steps[e].n_prev <= kSmallMax && pl.steps[e].n <= kSmallMax) ++e;
+                    // (a step that reads or writes by slot -- tiny LDS budgets in tests make WIDE steps of small cuts -- is not a small step)
+                    while (e < n_steps - 1 && pl.steps[e].n_prev <= kSmallMax && pl.steps[e].n <= kSmallMax && !pl.steps[e].src_slots && !pl.steps[e].stay) ++e;
                     if (e - s >= 2) {
                         const size_t lds = (2 * kSmallPitch * kSmallPitch + 3 * kSmallMax) * sizeof(float);
                         HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));

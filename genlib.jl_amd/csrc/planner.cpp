@@ -518,6 +518,25 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             }
         }
     }
+    // Memory: the two level buffers with in-place runs against plain alternation.  Usually less (one P x P matrix + the entry cut
+    // instead of two matrices of the widest cuts); several runs with large P in both buffers can need more -- then not in place.
+    if (stay_on) {
+        double need_s[2] = {0, 0}, need_p[2] = {0, 0};
+        int b = 0;
+        bool any = false;
+        for (int32_t c = 0; c + 1 < L; ++c) {
+            if (c >= 1) b = stay_c[c] ? b : 1 - b;
+            any = any || stay_c[c];
+            const double rows = static_cast<double>(slotP[c] > 0 ? slotP[c] : plan.cut_sizes[c]) + 1.0;
+            need_s[b] = std::max(need_s[b], rows * static_cast<double>(plan.ld[c]));
+            need_p[c & 1] = std::max(need_p[c & 1], (static_cast<double>(plan.cut_sizes[c]) + 1.0) * static_cast<double>(pitch_for(plan.cut_sizes[c])));
+        }
+        if (any && need_s[0] + need_s[1] > opt.stay_mem_ratio * (need_p[0] + need_p[1])) {
+            PlanOptions o2 = opt;
+            o2.no_stay = true;
+            return build_plan(n_ind, ind, father, mother, n_pro, pro_ids, o2, plan, err);
+        }
+    }
     const bool last_wide = L >= 2 && mode_for(plan.cut_sizes[L - 2], opt) == kModeWide;
     if (!last_wide) {
         cut[L - 1] = plan.final_members;

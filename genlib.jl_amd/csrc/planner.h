@@ -105,6 +105,7 @@ struct PlanOptions {
                                       // work order, the last cut in proband order): what the column-panel multi-GPU path needs
     bool no_stay = false;             // never keep WIDE levels in place (A/B and test hook)
     int64_t stay_max_slots = 200000;  // largest slot capacity P of a run (a P x P Float32 matrix: 160 GB)
+    double stay_mem_ratio = 1.2;      // in-place runs are dropped when the two level buffers would need more than this x plain alternation
     int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):
                                       // more of them = longer runs before the slot space is full (memory: P grows)
 };

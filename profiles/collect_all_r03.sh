@@ -15,6 +15,9 @@ for w in cfg4 cfg3 cfg2 cfg5 cfg4o; do
   rm -rf gpurun_out/prof_r03_$w
 done
 # secondary paths
+for w in cfg3 cfg2; do python bench.py --workload $w --storage f64 --steps 10 --warmup 2 > "$O/r03_bench_${w}_f64.json" 2> "$O/bench_${w}_f64.err"; done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_f64" -- python3 bench.py --workload cfg3 --storage f64 --steps 5 --warmup 1 > "$O/kt_f64.log" 2>&1
+find "$O/kt_f64" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/r03_cfg3_f64_kernel_stats.csv"; rm -rf "$O/kt_f64"
 for w in sparse140 sparse2k; do python bench.py --workload $w --steps 5 --warmup 1 > "$O/r03_bench_$w.json" 2> "$O/bench_$w.err"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_sparse" -- python3 bench.py --workload sparse140 --steps 3 --warmup 1 > "$O/kt_sparse.log" 2>&1
 find "$O/kt_sparse" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/r03_sparse140_kernel_stats.csv"; rm -rf "$O/kt_sparse"

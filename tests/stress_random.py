@@ -14,7 +14,52 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
-         "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN"]
+         "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
+         "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT"]
+
+
+def make_case(case):
+    """The pedigree, proband list and environment knobs of one random case (a pure function of `case`); `r` goes on drawing."""
+    from genlib_jl_amd import synth
+    r = np.random.default_rng(case)
+    n_gen = int(r.integers(3, 16))
+    n_pro = int(r.integers(5, 400))
+    n_ind = n_pro + (n_gen - 1) * int(r.integers(20, 500))
+    skip = int(r.choice([0, 0, 30, 150, 400, 650, 850]))
+    ind, fa, mo, sex, pro = synth.random_mating(n_ind, n_pro, n_gen, seed=case, skip_permille=skip)
+    if r.random() < 0.3:
+        mo = mo.copy(); mo[:: int(r.integers(7, 40))] = 0                   # one-parent members
+    if r.random() < 0.4:                                                  # probands: a subset, some ancestors, duplicates
+        extra = ind[r.integers(0, len(ind), size=int(r.integers(1, 20)))]
+        pro = np.concatenate([r.permutation(pro)[: max(2, n_pro // 2)], extra, pro[:2]])
+    env = {}
+    if r.random() < 0.7:
+        env["GENPHI_LDS_CAP_FLOATS"] = str(int(r.choice([64, 256, 700, 1500, 4096])))
+    if r.random() < 0.3:
+        env["GENPHI_FULL_MAX_FLOATS"] = "0"
+    if r.random() < 0.5:
+        env["GENPHI_CERT_MIN_EXP"] = str(int(r.integers(-27, 0)))
+    if r.random() < 0.3:
+        env["GENPHI_FAST_NT"] = str(int(r.choice([512, 1024])))
+    if r.random() < 0.15:
+        env["GENPHI_NO_FAST"] = "1"
+    if r.random() < 0.3:
+        env["GENPHI_MAX_CPT"] = str(int(r.choice([4, 8, 16])))
+    if r.random() < 0.2:
+        env["GENPHI_NO_SMALL"] = "1"
+    if r.random() < 0.2:
+        env["GENPHI_MAX_GROUP"] = str(int(r.choice([1, 3, 8])))
+    if r.random() < 0.5:
+        env["GENPHI_WIDE_ROUTE"] = str(r.choice(["A", "B"]))
+    if r.random() < 0.5:
+        env["GENPHI_MAX_RUN"] = str(int(r.choice([2, 7, 32, 1000])))             # hub walk with chain steps
+    if r.random() < 0.15:
+        env["GENPHI_NO_STAY"] = "1"                                               # WIDE levels never stay in place
+    elif r.random() < 0.4:
+        env["GENPHI_STAY_HEADROOM"] = str(int(r.choice([1, 2, 4])))               # longer in-place runs
+    if r.random() < 0.8:
+        env["GENPHI_STAY_MEM_PCT"] = "100000"                                     # (small cuts: the slot matrix is many times the plain buffers)
+    return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env
 
 
 def main():
@@ -24,41 +69,10 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed0)
-    t0, n_cases, n_fail = time.time(), 0, 0
+    t0, n_cases, n_fail, n_stay = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         case = int(rng.integers(1 << 30))
-        r = np.random.default_rng(case)
-        n_gen = int(r.integers(3, 16))
-        n_pro = int(r.integers(5, 400))
-        n_ind = n_pro + (n_gen - 1) * int(r.integers(20, 500))
-        skip = int(r.choice([0, 0, 30, 150, 400]))
-        ind, fa, mo, sex, pro = synth.random_mating(n_ind, n_pro, n_gen, seed=case, skip_permille=skip)
-        if r.random() < 0.3:
-            mo = mo.copy(); mo[:: int(r.integers(7, 40))] = 0                   # one-parent members
-        if r.random() < 0.4:                                                  # probands: a subset, some ancestors, duplicates
-            extra = ind[r.integers(0, len(ind), size=int(r.integers(1, 20)))]
-            pro = np.concatenate([r.permutation(pro)[: max(2, n_pro // 2)], extra, pro[:2]])
-        env = {}
-        if r.random() < 0.7:
-            env["GENPHI_LDS_CAP_FLOATS"] = str(int(r.choice([64, 256, 700, 1500, 4096])))
-        if r.random() < 0.3:
-            env["GENPHI_FULL_MAX_FLOATS"] = "0"
-        if r.random() < 0.5:
-            env["GENPHI_CERT_MIN_EXP"] = str(int(r.integers(-27, 0)))
-        if r.random() < 0.3:
-            env["GENPHI_FAST_NT"] = str(int(r.choice([512, 1024])))
-        if r.random() < 0.15:
-            env["GENPHI_NO_FAST"] = "1"
-        if r.random() < 0.3:
-            env["GENPHI_MAX_CPT"] = str(int(r.choice([4, 8, 16])))
-        if r.random() < 0.2:
-            env["GENPHI_NO_SMALL"] = "1"
-        if r.random() < 0.2:
-            env["GENPHI_MAX_GROUP"] = str(int(r.choice([1, 3, 8])))
-        if r.random() < 0.5:
-            env["GENPHI_WIDE_ROUTE"] = str(r.choice(["A", "B"]))
-        if r.random() < 0.5:
-            env["GENPHI_MAX_RUN"] = str(int(r.choice([2, 7, 32, 1000])))             # hub walk with chain steps
+        r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env = make_case(case)
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -73,6 +87,7 @@ def main():
         what = []
         try:
             pl = gen.plan(ped, pro)
+            n_stay += sum(pl.step_slots(k)[0] & 1 for k in range(len(pl.step_modes())))
             if not np.array_equal(pl.compute(), want):
                 what.append("full")
             if n > 2:
@@ -105,7 +120,7 @@ def main():
             print(f"FAIL case={case} gens={n_gen} n_ind={n_ind} n_pro={n_pro} skip={skip} env={env} -> {what}", flush=True)
         if n_cases % 20 == 0:
             print(f"... {n_cases} cases, {n_fail} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"stress: {n_cases} cases, {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
+    print(f"stress: {n_cases} cases ({n_stay} in-place WIDE steps among them), {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
     return 1 if n_fail else 0
 
 

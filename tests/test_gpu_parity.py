@@ -764,7 +764,9 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
     for cap, args, kw in [(3000, (20000, 300, 18), dict(skip_permille=500, seed=2)),
                           (2000, (30000, 400, 30), dict(skip_permille=600, seed=3)),
                           (1200, (12000, 500, 24), dict(skip_permille=700, seed=8)),
-                          (900, (8000, 300, 20), dict(skip_permille=800, seed=21))]:
+                          (900, (8000, 300, 20), dict(skip_permille=800, seed=21)),
+                          (64, (1046, 388, 15), dict(skip_permille=150, seed=213737704)),      # tiny cuts: < 64 new members per step, steps
+                          (64, (786, 255, 10), dict(skip_permille=30, seed=499794305))]:       # next to the fused small-level run
         ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
         ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
         want = oracle.Pedigree(ind, fa, mo).phi(pro)
@@ -773,6 +775,7 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
             for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM"):
                 monkeypatch.delenv(k, raising=False)
             monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+            monkeypatch.setenv("GENPHI_STAY_MEM_PCT", "1000")      # (small cuts: the slot matrix may exceed 1.2 x the plain buffers)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             pl = gen.plan(ped, pro)
@@ -782,7 +785,7 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
             if "GENPHI_NO_STAY" in env:
                 assert n_stay == 0 and all(f == (0, 0, 0, 0) for f in flags)
             else:
-                assert n_stay >= 2, flags
+                assert n_stay >= 2 or cap == 64, flags
                 stays += n_stay
                 for k, f in enumerate(flags):
                     if f[0] & 1:                     # in place: reads and writes by slot, the next step reads by slot too
@@ -796,7 +799,7 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
             _assert_equal(np.concatenate(parts, axis=0), want)
             pl.close()
     assert stays >= 100
-    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM"):
+    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT"):
         monkeypatch.delenv(k, raising=False)
 
 

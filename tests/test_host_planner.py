@@ -309,3 +309,49 @@ def test_hub_walk_work_lists(monkeypatch):
                 assert full < 0.9 * staged_walk                                          # chaining stages fewer rows than one run per hub
     monkeypatch.delenv("GENPHI_FULL_MAX_FLOATS", raising=False)
     monkeypatch.delenv("GENPHI_MAX_RUN", raising=False)
+
+
+def test_wide_runs_planned_in_place(monkeypatch):
+    """Persistent slots (csrc/planner.h LevelStep::stay), planner side, no GPU: on overlapping generations whose cuts exceed a small
+    LDS budget the planner keeps runs of WIDE steps in place; a step that writes in place reads by slot and so does the step after
+    it; the slot capacity holds the cut and the new members; the cut sizes and dragged counts do not depend on any of it (they are
+    the oracle-checked ones); GENPHI_NO_STAY and a tiny GENPHI_STAY_MAX_SLOTS switch it off; more head room makes longer runs."""
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(30000, 400, 30, skip_permille=600, seed=3)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", "2000")
+    monkeypatch.setenv("GENPHI_STAY_MEM_PCT", "1000")
+
+    def plan_of(**env):
+        for k in ("GENPHI_NO_STAY", "GENPHI_STAY_MAX_SLOTS", "GENPHI_STAY_HEADROOM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, pro)
+        sizes, both = pl.levels()
+        modes = pl.step_modes()
+        slots = [pl.step_slots(k) for k in range(len(modes))]
+        pl.close()
+        return sizes, both, modes, slots
+
+    sizes, both, modes, slots = plan_of()
+    stay = [k for k, f in enumerate(slots) if f[0] & 1]
+    assert len(stay) >= 8 and all(modes[k] == 2 for k in stay)
+    for k in stay:
+        flags, P, p0, npad = slots[k]
+        assert flags & 2 and slots[k + 1][0] & 2 and modes[k + 1] == 2           # reads by slot; so does the next step, a WIDE one
+        assert P % 64 == 0 and p0 % 64 == 0 and npad % 64 == 0 and p0 < P
+        assert npad >= sizes[k + 1] - both[k] and P >= sizes[k] + npad           # room for the source cut and the new members
+        assert sizes[k + 1] >= 2 * (sizes[k + 1] - both[k])                      # worth it: at least as many dragged as new members
+    for k, f in enumerate(slots):
+        if f[0] == 2:                                                            # the step that leaves a run: reads by slot, writes compactly
+            assert slots[k - 1][0] & 1 and slots[k - 1][1] == f[1]
+    for env in ({"GENPHI_NO_STAY": "1"}, {"GENPHI_STAY_MAX_SLOTS": "128"}):
+        s2, b2, m2, sl2 = plan_of(**env)
+        assert (s2, b2, m2) == (sizes, both, modes) and all(f == (0, 0, 0, 0) for f in sl2)
+    s3, b3, m3, sl3 = plan_of(GENPHI_STAY_HEADROOM="3")
+    assert (s3, b3, m3) == (sizes, both, modes) and sum(f[0] & 1 for f in sl3) >= len(stay)
+    # the memory guard: runs whose slot matrices need more than the given share of the plain level buffers are dropped
+    s4, b4, m4, sl4 = plan_of(GENPHI_STAY_HEADROOM="3", GENPHI_STAY_MEM_PCT="101")
+    assert (s4, b4, m4) == (sizes, both, modes) and all(f == (0, 0, 0, 0) for f in sl4)
