@@ -32,6 +32,11 @@ def csrc_sha16(root=None):
     return h.hexdigest()[:16]
 
 
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
+dst = os.path.join(root, "profiles")
+
+
 def one(pattern):
     return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)     # newest run in that directory
 
@@ -53,7 +58,8 @@ try:
     T = agg(one("pmc_tcp/*/*counter_collection.csv"))      # requests from the CUs into L2 (64-byte requests)
 except Exception:
     T = {}
-KERNELS = ("level_", "levels_small", "rows_compact", "transpose_block", "copy_block", "pad_zero", "colperm", "group_split")
+KERNELS = ("level_", "levels_small", "rows_compact", "rows_avg", "drag_rows", "transpose_block", "transpose_slots", "slots_scatter", "slots_clear",
+           "copy_block", "pad_zero", "colperm", "group_split")
 rows, tot, sweeps, steps = [], 0.0, 0, 0
 for k in F:
     name = F[k]["name"]
@@ -90,6 +96,7 @@ json.dump({"workload": wl, "tag": tag, "csrc_sha16": csrc_sha16(root), "sweeps_p
            "hbm_bytes_per_launch": per_step,
            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE in separate passes, "
                      "KiB -> bytes, summed over every kernel of the profiled gen.phi sweeps; per launch = per level step "
-                     "(a WIDE level step is several kernels)"},
+                     "(a WIDE level step is several kernels)",
+           "csrc_sha16_note": "fingerprint of genphi_hip.hip, planner.cpp, planner.h, panel_launch.h (the dense path) as collected"},
           open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
 print(f"{len(rows)} dispatches, {sweeps} sweeps, {tot / sweeps / 1e9:.2f} GB per sweep" + (f", {per_step / 1e9:.3f} GB per level step" if per_step else ""))
