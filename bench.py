@@ -464,7 +464,8 @@ def main():
         ceiling, ceiling_src = measured_ceiling()
         traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath) and not f64:
+        # (the committed traffic files were collected with the default settings: not comparable under A/B hooks that change what moves)
+        if os.path.exists(tpath) and not f64 and not os.environ.get("GENPHI_NO_STAY"):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")

@@ -123,6 +123,9 @@ def replicated_bytes(cut_sizes, wide_last=False):
         total += (n_last + 1) * pitch(n_last) + tail
     if max(cut_sizes[:-1], default=0) > 36863:         # WIDE steps (a source row does not fit in LDS): psi_p
         total += max(need)
+        # runs of WIDE steps may stay in place: ONE slot matrix instead of two ping-pong ones -- the planner drops
+        # the runs when that needs more than 1.2 x the plain buffers (PlanOptions::stay_mem_ratio), so that is the bound
+        total += (need[0] + need[1]) // 5
     return 4 * total + 30 * sum(cut_sizes)
 
 
