@@ -1684,6 +1684,7 @@ struct Tuning {
     int stay_max_slots = 0;        // GENPHI_STAY_MAX_SLOTS   test: largest slot capacity of an in-place run (default: planner.h)
     int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
+    bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
                                    //                         larger: the walk chains from hub to hub (16-20 % fewer staged rows, measured no faster:
@@ -1718,6 +1719,7 @@ static Tuning tuning_from_env()
     t.stay_max_slots = geti("GENPHI_STAY_MAX_SLOTS", 0);
     t.stay_headroom = geti("GENPHI_STAY_HEADROOM", -1);
     t.stay_mem_pct = geti("GENPHI_STAY_MEM_PCT", 0);
+    t.stay_scatter = geti("GENPHI_STAY_SCATTER", 0) != 0;
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -1936,6 +1938,7 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.lds_cap_floats >= 16) p->popt.lds_cap_floats = p->tun.lds_cap_floats;
     if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
     p->popt.no_stay = p->tun.no_stay;
+    p->popt.stay_scatter = p->tun.stay_scatter;
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     if (p->tun.stay_mem_pct > 0) p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0;
@@ -1988,7 +1991,7 @@ int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
     if (!plan || !info || step < 0 || step >= static_cast<int32_t>(plan->plan.steps.size()))
         return fail(GENPHI_ERR_ARG, "genphi_plan_step_slots: bad argument");
     const LevelStep &s = plan->plan.steps[step];
-    info[0] = (s.stay ? 1 : 0) | (s.src_slots ? 2 : 0);
+    info[0] = (s.stay ? 1 : 0) | (s.src_slots ? 2 : 0) | (s.stay && s.contig ? 4 : 0);
     info[1] = s.stay ? plan->plan.ld[step + 1] : (s.src_slots ? s.P : 0);
     info[2] = s.p0; info[3] = s.npad;
     return GENPHI_OK;
@@ -2656,17 +2659,18 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         //    columns into the cut's; the `lead` placeholder columns (zeros) land on columns
         //    [nd - lead, nd) of the new rows, which pass 3 overwrites.  The sub-step also writes the
         //    zero padding [n, ld) of its rows.
-        const long long shift = nd - nn.lead;
+        const bool scatter = stay && !s.contig;                 // the new members' slots are not one stretch: through a compact buffer
+        const long long shift = stay ? s.p0 : nd - nn.lead;
         LevelCtx cn;
         cn.s = &nn; cn.d = &dn; cn.slot = static_cast<int>(p->plan.steps.size()) + 1 + d.nn;
         cn.cert_prev = p->d_cert_p;
-        cn.cert_out = stay ? p->d_cert_t : cert_out + shift;
+        cn.cert_out = scatter ? p->d_cert_t : cert_out + shift;
         cn.identity = false; cn.dbg = false; cn.no_none_row = true;
-        // (in place: the block goes to a compact buffer of its own -- the sub-step's pitch is npad -- and from there to the new
-        // members' rows and columns)
-        const int rc = launch_level(p, cn, p->psi_p, stay ? p->nn_tmp : out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
+        // (in place with scattered slots: the block goes to a compact buffer of its own -- the sub-step's pitch is npad -- and
+        // from there to the new members' rows and columns; with the slots in one stretch it is written where it belongs)
+        const int rc = launch_level(p, cn, p->psi_p, scatter ? p->nn_tmp : out + shift * (s.ld + 1), dn.work, nullptr, n_new, 0, dn.groups);
         if (rc) return rc;
-        if (stay) {
+        if (scatter) {
             hipLaunchKernelGGL(slots_scatter_kernel, dim3(static_cast<unsigned>(n_new)), dim3(256), 0, p->stream, p->nn_tmp, static_cast<long long>(nn.ld),
                                n_new, d.blk_slot, out, static_cast<long long>(s.ld), p->d_cert_t, cert_out);
             HIP_TRY(hipGetLastError());

@@ -420,7 +420,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     // ---- runs of WIDE steps whose members stay in place (see LevelStep::stay) ---------------------------------
     // stay_c[c]: the step producing cut c writes in place; slotP[c] > 0: cut c is stored by slot, capacity slotP[c];
     // slots_c[c][k]: slot of member k of cut c; abs?_c[c][k]: slots of the sources (in cut c - 1) of member k of cut c
-    std::vector<char> stay_c(L, 0);
+    std::vector<char> stay_c(L, 0), contig_c(L, 0);
     std::vector<int32_t> slotP(L, 0), npad_c(L, 0);
     std::vector<std::vector<int32_t>> slots_c(L), absA_c(L), absB_c(L), gran_c(L);
     if (stay_on) {
@@ -488,14 +488,31 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             for (int32_t cc = c; cc <= e; ++cc) {
                 const int64_t n_new = static_cast<int64_t>(new_of[cc].size()), need = (n_new + 63) / 64;
                 got.clear();
+                auto free_gran = [&](int64_t g) {
+                    for (int64_t q = 64 * g; q < 64 * g + 64; ++q) if (last_at[q] >= cc - 1) return false;       // (free: gone before the source cut)
+                    return true;
+                };
+                // first choice: ONE stretch of free granules (the new x new block is then written in place, not scattered)
                 int64_t g = gpos;
-                for (int64_t scanned = 0; scanned < n_gran && static_cast<int64_t>(got.size()) < need; ++scanned, g = (g + 1) % n_gran) {
-                    bool free_g = true;
-                    for (int64_t q = 64 * g; q < 64 * g + 64 && free_g; ++q) free_g = last_at[q] < cc - 1;      // gone before the source cut
-                    if (free_g) got.push_back(static_cast<int32_t>(64 * g));
+                {
+                    int64_t run_len = 0, s0 = -1;
+                    for (int64_t scanned = 0, gg = gpos; scanned < n_gran + need && s0 < 0 && need > 0; ++scanned, gg = (gg + 1) % n_gran) {
+                        if (gg == 0) run_len = 0;                    // a stretch does not wrap
+                        run_len = free_gran(gg) ? run_len + 1 : 0;
+                        if (run_len >= need) s0 = gg - need + 1;
+                    }
+                    if (s0 >= 0) { for (int64_t k = 0; k < need; ++k) got.push_back(static_cast<int32_t>(64 * (s0 + k))); g = (s0 + need) % n_gran; }
+                }
+                const bool contig = need > 0 && static_cast<int64_t>(got.size()) == need && !opt.stay_scatter;
+                if (!contig) {
+                    got.clear();
+                    g = gpos;
+                    for (int64_t scanned = 0; scanned < n_gran && static_cast<int64_t>(got.size()) < need; ++scanned, g = (g + 1) % n_gran)
+                        if (free_gran(g)) got.push_back(static_cast<int32_t>(64 * g));
                 }
                 if (static_cast<int64_t>(got.size()) < need) break;  // the slot space is full: this step copies the cut out (and may start a new run)
                 gpos = g;
+                contig_c[cc] = contig ? 1 : 0;
                 sources(cc);                                         // (before the new members get their slots)
                 const size_t n = cut[cc].size(), nd = n - static_cast<size_t>(n_new);
                 slots_c[cc].resize(n);
@@ -605,7 +622,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             st.absA = std::move(absA_c[c]); st.absB = std::move(absB_c[c]);
         }
         if (stay_c[c]) {
-            st.stay = true; st.npad = npad_c[c]; st.out_slots = slots_c[c]; st.blk_slot = gran_c[c];
+            st.stay = true; st.npad = npad_c[c]; st.out_slots = slots_c[c]; st.blk_slot = gran_c[c]; st.contig = contig_c[c] != 0;
             st.p0 = st.blk_slot.empty() ? 0 : st.blk_slot[0];
             // slot ranges that hold the dragged members (gaps of up to 255 dead slots are bridged): what the new columns are written to
             std::vector<int32_t> ds(st.out_slots.begin(), st.out_slots.begin() + dragged);
@@ -648,7 +665,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         nn.lead = static_cast<int32_t>(lead);
         nn.n_prev = n_par; nn.n = lead + n_new;
         // (... and writes the block into a buffer of its own, pitch npad, that is scattered to the new members' slots afterwards)
-        nn.ld_prev = pitch_for(n_par); nn.ld = st.stay ? st.npad : st.ld; nn.width = st.stay ? st.npad : st.width - (dragged - lead);
+        // (... unless the new members' slots are one stretch: then in place, at [p0, p0 + npad))
+        nn.ld_prev = pitch_for(n_par); nn.ld = (st.stay && !st.contig) ? st.npad : st.ld; nn.width = st.stay ? st.npad : st.width - (dragged - lead);
         nn.mode = nn_mode;
         nn.srcA.resize(nn.n); nn.srcB.resize(nn.n); nn.ord.resize(nn.n);
         const int32_t pnone = static_cast<int32_t>(n_par);

@@ -77,6 +77,7 @@ struct LevelStep {
     //               64 * granules >= n_new slots reserved; p0 = the first granule, diagnostic)
     //   out_slots   slot of every member of the output cut (stay steps)
     bool src_slots = false, stay = false;
+    bool contig = false;              // (stay) the new members' slots are ONE stretch [p0, p0 + npad): the new x new block is written in place
     int32_t P = 0, p0 = 0, npad = 0;
     std::vector<int32_t> absA, absB, parents_abs, out_slots, blk_slot;
     std::vector<int32_t> live_ranges;      // (stay) [lo, hi) slot ranges, 64-aligned, ascending, that hold the dragged members
@@ -104,6 +105,7 @@ struct PlanOptions {
     bool indices_only = false;        // cuts and per-member sources / rank words only (every step marked FULL, no pk words, no
                                       // work order, the last cut in proband order): what the column-panel multi-GPU path needs
     bool no_stay = false;             // never keep WIDE levels in place (A/B and test hook)
+    bool stay_scatter = false;        // in-place steps never write their new x new block in place (A/B and test hook: always through the compact buffer)
     int64_t stay_max_slots = 200000;  // largest slot capacity P of a run (a P x P Float32 matrix: 160 GB)
     double stay_mem_ratio = 1.2;      // in-place runs are dropped when the two level buffers would need more than this x plain alternation
     int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):

@@ -104,7 +104,8 @@ int genphi_plan_step_info(const genphi_plan *plan, int32_t step, int64_t *info);
 /* Diagnostic: how WIDE level step `step` stores its cuts in the Float32 sweep (persistent slots, csrc/planner.h LevelStep::stay).
  * info[0] = 1 when the step writes its cut IN PLACE (members keep their row / column slot in one matrix: only the new rows and
  * columns are written, the dragged x dragged block -- src/compute.jl:108-110 -- is not copied) | 2 when it reads a cut stored by
- * slot; info[1] = slot capacity (row pitch) of that matrix, info[2] / info[3] = first slot / reserved slots of the new members.
+ * slot | 4 when the new members' slots are one stretch (their new x new block is then written in place instead of scattered);
+ * info[1] = slot capacity (row pitch) of that matrix, info[2] / info[3] = first slot / reserved slots of the new members.
  * All zero for every other step.                                                                                               */
 int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info);
 
