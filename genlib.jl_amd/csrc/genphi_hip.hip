@@ -1684,6 +1684,7 @@ struct Tuning {
     int stay_max_slots = 0;        // GENPHI_STAY_MAX_SLOTS   test: largest slot capacity of an in-place run (default: planner.h)
     int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
+    int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
     bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
@@ -1720,6 +1721,7 @@ static Tuning tuning_from_env()
     t.stay_headroom = geti("GENPHI_STAY_HEADROOM", -1);
     t.stay_mem_pct = geti("GENPHI_STAY_MEM_PCT", 0);
     t.stay_scatter = geti("GENPHI_STAY_SCATTER", 0) != 0;
+    t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -1939,6 +1941,7 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
     p->popt.no_stay = p->tun.no_stay;
     p->popt.stay_scatter = p->tun.stay_scatter;
+    if (p->tun.stay_slack_pct >= 0) p->popt.stay_slack_pct = p->tun.stay_slack_pct;
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     if (p->tun.stay_mem_pct > 0) p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0;

@@ -455,7 +455,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                 P = std::max(P, size_of[cc - 1] + pad64(static_cast<int64_t>(new_of[cc].size())));
                 blk = std::max(blk, pad64(static_cast<int64_t>(new_of[cc].size())));
             }
-            P = pad64(P + P / 16 + 64) + std::max(0, opt.stay_headroom) * blk;      // ~6 % of slack for granules that are only partly dead
+            P = pad64(P + P * std::max(0, opt.stay_slack_pct) / 100 + 64) + std::max(0, opt.stay_headroom) * blk;      // slack for granules that are only partly dead
             if (P > opt.stay_max_slots || P >= (int64_t(1) << 30)) { c = e + 1; continue; }
             // the entry cut c - 1 sits at slots [0, n) of the matrix (written compactly, with pitch P, by its own step)
             const std::vector<int32_t> &ent = cut[c - 1];
