@@ -799,6 +799,19 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
             _assert_equal(np.concatenate(parts, axis=0), want)
             pl.close()
     assert stays >= 100
+    # a real genealogy (irregular generation gaps: members of one block leave at many different steps), wide levels forced
+    ped = gen.genealogy(gen.genea140)
+    pro = gen.pro(ped)
+    want = oracle.Pedigree.from_file(gen.genea140).phi(pro)
+    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_SCATTER"):
+        monkeypatch.delenv(k, raising=False)
+    for cap in (8000, 4000):
+        monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
+        pl = gen.plan(ped, pro)
+        assert sum(pl.step_slots(k)[0] & 1 for k in range(len(pl.step_modes()))) >= 1
+        _assert_equal(pl.compute(), want)
+        _assert_equal(pl.compute(), want)
+        pl.close()
     for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER"):
         monkeypatch.delenv(k, raising=False)
 
