@@ -1261,6 +1261,69 @@ transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict_
     }
 }
 
+// In-place WIDE steps, new x dragged AND dragged x new in one pass: a workgroup computes a tile of 64 new rows (one granule) x
+// kFT columns of a slot range that holds dragged members,
+//   v = RN32((m[f_r][c] + m[m_r][c]) / 2)      (a wave reads 1 KB of a parent row: 256 columns)
+// stores it into the new rows (m[slot(r)][c], 1 KB runs) and, through LDS, transposed into the new columns of the rows c
+// (m[c][slot(r)], 256-byte runs) -- the new rows are not read back.  rowdesc: the step's new rows in granule order
+// (A, B, output row = slot, scale).  Source and destination are the same matrix: the tile's rows and the new columns hold no
+// member of the source cut.  Certificates of both the new rows and the rows c.
+constexpr int kFT = 256;
+__global__ void __launch_bounds__(256)
+rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ rowdesc, int n_new, const int *__restrict__ blk_slot,
+                  int c_lo, int cols, int *__restrict__ cert_out, unsigned cert_thresh)
+{
+    extern __shared__ float tile_dyn[];                          // [64][kFT + 1]
+    float (*tile)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(tile_dyn);
+    const int g = blockIdx.y, c0 = c_lo + blockIdx.x * kFT, c_hi = c_lo + cols;
+    const int base = blk_slot[g], rows_here = min(64, n_new - g * 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = c0 + lane * 4;                                // this lane's four columns (ranges are multiples of 64 columns)
+    const bool in = c < c_hi;
+    // ---- new x dragged: 16 rows per wave, four at a time (eight 16-byte loads in flight) ----
+    for (int r0 = w * 16; r0 < w * 16 + 16; r0 += 4) {
+        int4 d[4];
+        f4_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = rowdesc[g * 64 + min(r0 + u, rows_here - 1)];
+            const int cc = in ? c : c_lo;                        // (clamped: unconditional loads)
+            a[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].x * ld + cc);
+            b[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].y * ld + cc);       // ("none" is the all-zero row)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            if (r >= rows_here) break;                           // (wave-uniform)
+            const double sc = d[u].w == 0 ? 1.0 : 0.5;
+            f4_t v;
+            unsigned ck = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = static_cast<float>((static_cast<double>(a[u][e]) + static_cast<double>(b[u][e])) * sc);
+                tile[r][lane * 4 + e] = v[e];
+                ck = min(ck, cert_key(v[e]));
+            }
+            if (in) {
+                *reinterpret_cast<f4_t *>(m + (long long)d[u].z * ld + c) = v;
+                if (cert_out && ck < cert_thresh) cert_out[d[u].z] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- dragged x new: column k of the tile is a 256-byte run of row c0 + k ----
+    const int tx = lane;
+    for (int k = w; k < kFT; k += 4) {
+        const int cr = c0 + k;
+        if (cr < c_hi && tx < rows_here) {
+            const float v = tile[tx][k];
+            m[(long long)cr * ld + base + tx] = v;
+            if (cert_out && cert_key(v) < cert_thresh) cert_out[cr] = 1;
+        }
+    }
+    (void)none;
+}
+
 // zero padding of a level matrix: columns [n, ld) of rows 0..n-1 and the whole "none" row n
 // (width <= ld: the columns the level owns -- the entry cut of an in-place run has the run's pitch, but only its own width is padded)
 __global__ void __launch_bounds__(256) pad_zero_kernel(float *__restrict__ m, long long ld, int n, long long width)
@@ -1685,6 +1748,7 @@ struct Tuning {
     int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
+    bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
     bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
     int max_run = 1;               // GENPHI_MAX_RUN          tuning: stages per run of the hub walk.  1 (default): a run is one hub and its children;
@@ -1721,6 +1785,7 @@ static Tuning tuning_from_env()
     t.stay_headroom = geti("GENPHI_STAY_HEADROOM", -1);
     t.stay_mem_pct = geti("GENPHI_STAY_MEM_PCT", 0);
     t.stay_scatter = geti("GENPHI_STAY_SCATTER", 0) != 0;
+    t.stay_two_pass = geti("GENPHI_STAY_TWO_PASS", 0) != 0;
     t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
@@ -2692,6 +2757,19 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     //   24.9 -> 27.8 ms).  GENPHI_WIDE_ROUTE = A | B forces one (A/B hook); default: B iff nd / n_prev < 2/3.
     if (stay) {
         if (nn_naive) return fail(GENPHI_ERR_ARG, "internal: an in-place WIDE step without a row kernel for its new x new block");
+        if (!p->tun.stay_two_pass) {
+            // 3S + 4S fused: new x dragged and its transpose in one pass over the parents' rows (rows_avg_t_kernel)
+            const size_t lds = 64 * (kFT + 1) * sizeof(float);
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(rows_avg_t_kernel), lds));
+            for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) {
+                const int c_lo = s.live_ranges[h], len = s.live_ranges[h + 1] - c_lo;
+                dim3 gt(static_cast<unsigned>((len + kFT - 1) / kFT), static_cast<unsigned>(n_gran));
+                hipLaunchKernelGGL(rows_avg_t_kernel, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
+                                   d.blk_slot, c_lo, len, cert_out, thr);
+                HIP_TRY(hipGetLastError());
+            }
+            return GENPHI_OK;
+        }
         // 3S. new x dragged: the new rows at the dragged members' columns, from the parents' rows of the same matrix
         {
             dim3 grid(static_cast<unsigned>(n_new), static_cast<unsigned>((nd + 2047) / 2048));

@@ -624,16 +624,21 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         if (stay_c[c]) {
             st.stay = true; st.npad = npad_c[c]; st.out_slots = slots_c[c]; st.blk_slot = gran_c[c]; st.contig = contig_c[c] != 0;
             st.p0 = st.blk_slot.empty() ? 0 : st.blk_slot[0];
-            // slot ranges that hold the dragged members (gaps of up to 255 dead slots are bridged): what the new columns are written to
-            std::vector<int32_t> ds(st.out_slots.begin(), st.out_slots.begin() + dragged);
-            std::sort(ds.begin(), ds.end());
-            for (size_t k = 0; k < ds.size();) {
-                size_t e = k;
-                while (e + 1 < ds.size() && ds[e + 1] - ds[e] <= 256) ++e;
-                const int32_t lo = ds[k] / 64 * 64, hi = std::min<int32_t>((ds[e] + 64) / 64 * 64, st.P);     // 64-aligned: 256-byte destination runs
-                if (!st.live_ranges.empty() && lo <= st.live_ranges.back()) st.live_ranges.back() = std::max(st.live_ranges.back(), hi);
-                else { st.live_ranges.push_back(lo); st.live_ranges.push_back(hi); }
-                k = e + 1;
+            // slot ranges (whole granules) that hold the dragged members: what the new columns are written to.  Gaps of up to three
+            // dead granules are bridged (fewer, longer launches; nothing reads a dead slot) -- never across a granule of this step's
+            // new members: their columns belong to the new x new block.
+            {
+                const int32_t n_gran = st.P / 64;
+                std::vector<char> gl(static_cast<size_t>(n_gran), 0);
+                for (int64_t k = 0; k < dragged; ++k) gl[st.out_slots[k] / 64] = 1;
+                for (int32_t b : st.blk_slot) gl[b / 64] = 2;
+                for (int32_t g = 0; g < n_gran;) {
+                    if (gl[g] != 1) { ++g; continue; }
+                    int32_t e = g;                                   // last live granule of the range
+                    for (int32_t h = g + 1; h < n_gran && h - e <= 4 && gl[h] != 2; ++h) if (gl[h] == 1) e = h;
+                    st.live_ranges.push_back(64 * g); st.live_ranges.push_back(64 * (e + 1));
+                    g = e + 1;
+                }
             }
         }
 

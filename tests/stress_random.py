@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
-         "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER"]
+         "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS"]
 
 
 def make_case(case):
@@ -57,6 +57,8 @@ def make_case(case):
         env["GENPHI_NO_STAY"] = "1"                                               # WIDE levels never stay in place
     elif r.random() < 0.4:
         env["GENPHI_STAY_HEADROOM"] = str(int(r.choice([1, 2, 4])))               # longer in-place runs
+    if r.random() < 0.3:
+        env["GENPHI_STAY_TWO_PASS"] = "1"                                         # new x dragged and its transpose as two kernels
     if r.random() < 0.3:
         env["GENPHI_STAY_SCATTER"] = "1"                                          # the new x new block always through the compact buffer
     if r.random() < 0.8:

@@ -771,8 +771,9 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
         ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
         want = oracle.Pedigree(ind, fa, mo).phi(pro)
         for env in ({}, {"GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_STAY_HEADROOM": "3"},
-                    {"GENPHI_STAY_HEADROOM": "2", "GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_STAY_SCATTER": "1"}, {"GENPHI_NO_STAY": "1"}):
-            for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_SCATTER"):
+                    {"GENPHI_STAY_HEADROOM": "2", "GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_STAY_SCATTER": "1"}, {"GENPHI_STAY_TWO_PASS": "1", "GENPHI_CERT_MIN_EXP": "-6"},
+                    {"GENPHI_NO_STAY": "1"}):
+            for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS"):
                 monkeypatch.delenv(k, raising=False)
             monkeypatch.setenv("GENPHI_LDS_CAP_FLOATS", str(cap))
             monkeypatch.setenv("GENPHI_STAY_MEM_PCT", "1000")      # (small cuts: the slot matrix may exceed 1.2 x the plain buffers)
@@ -812,7 +813,7 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
         _assert_equal(pl.compute(), want)
         _assert_equal(pl.compute(), want)
         pl.close()
-    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER"):
+    for k in ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_LDS_CAP_FLOATS", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS"):
         monkeypatch.delenv(k, raising=False)
 
 
