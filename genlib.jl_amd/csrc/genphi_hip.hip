@@ -1271,11 +1271,14 @@ transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict_
 constexpr int kFT = 256;
 __global__ void __launch_bounds__(256)
 rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ rowdesc, int n_new, const int *__restrict__ blk_slot,
-                  int c_lo, int cols, int *__restrict__ cert_out, unsigned cert_thresh)
+                  int c_lo, int cols, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest)
 {
     extern __shared__ float tile_dyn[];                          // [64][kFT + 1]
     float (*tile)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(tile_dyn);
-    const int g = blockIdx.y, c0 = c_lo + blockIdx.x * kFT, c_hi = c_lo + cols;
+    // (gran_fastest: consecutive workgroups take the SAME columns of different granules -- a parent's row piece is then read by
+    // its children's workgroups close in time)
+    const int g = gran_fastest ? blockIdx.x : blockIdx.y, ct = gran_fastest ? blockIdx.y : blockIdx.x;
+    const int c0 = c_lo + ct * kFT, c_hi = c_lo + cols;
     const int base = blk_slot[g], rows_here = min(64, n_new - g * 64);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = c0 + lane * 4;                                // this lane's four columns (ranges are multiples of 64 columns)
@@ -1748,6 +1751,7 @@ struct Tuning {
     int stay_headroom = -1;        // GENPHI_STAY_HEADROOM    tuning: extra blocks of free slots per in-place run (longer runs, more memory)
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
+    bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
     bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
     bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
     int max_group = 8;             // GENPHI_MAX_GROUP        tuning: children per segment of the SPLIT work lists (<= 8; <= 4 where rank masks are kept)
@@ -1786,6 +1790,7 @@ static Tuning tuning_from_env()
     t.stay_mem_pct = geti("GENPHI_STAY_MEM_PCT", 0);
     t.stay_scatter = geti("GENPHI_STAY_SCATTER", 0) != 0;
     t.stay_two_pass = geti("GENPHI_STAY_TWO_PASS", 0) != 0;
+    t.stay_col_fastest = geti("GENPHI_STAY_COL_FASTEST", 0) != 0;
     t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
@@ -2763,9 +2768,11 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(rows_avg_t_kernel), lds));
             for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) {
                 const int c_lo = s.live_ranges[h], len = s.live_ranges[h + 1] - c_lo;
-                dim3 gt(static_cast<unsigned>((len + kFT - 1) / kFT), static_cast<unsigned>(n_gran));
+                const int gf = p->tun.stay_col_fastest ? 0 : 1;
+                const unsigned nct = static_cast<unsigned>((len + kFT - 1) / kFT);
+                dim3 gt(gf ? static_cast<unsigned>(n_gran) : nct, gf ? nct : static_cast<unsigned>(n_gran));
                 hipLaunchKernelGGL(rows_avg_t_kernel, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
-                                   d.blk_slot, c_lo, len, cert_out, thr);
+                                   d.blk_slot, c_lo, len, cert_out, thr, gf);
                 HIP_TRY(hipGetLastError());
             }
             return GENPHI_OK;
