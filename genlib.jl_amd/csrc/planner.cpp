@@ -443,7 +443,8 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         auto can = [&](int32_t c) {
             // (worth it while the dragged x dragged block that is not copied outweighs the new rows: late levels of shrinking cuts
             // have few dragged members, and reading a cut by slot costs the next step its faster route)
-            return c >= 2 && wide_step(c) && c + 1 < L && wide_step(c + 1) && cut[c].size() >= 2 * new_of[c].size() && nn_ok(c) && nn_ok(c + 1);
+            return c >= 2 && wide_step(c) && c + 1 < L && wide_step(c + 1) && 100 * static_cast<int64_t>(cut[c].size()) >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
+                   cut[c].size() > new_of[c].size() && nn_ok(c) && nn_ok(c + 1);
         };
         std::vector<int32_t> last_at;                                // per slot: last cut of its occupant (-1: free)
         for (int32_t c = 1; c + 1 < L;) {

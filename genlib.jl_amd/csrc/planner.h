@@ -108,6 +108,7 @@ struct PlanOptions {
     bool stay_scatter = false;        // in-place steps never write their new x new block in place (A/B and test hook: always through the compact buffer)
     int64_t stay_max_slots = 200000;  // largest slot capacity P of a run (a P x P Float32 matrix: 160 GB)
     double stay_mem_ratio = 1.2;      // in-place runs are dropped when the two level buffers would need more than this x plain alternation
+    int32_t stay_min_ratio_pct = 200; // a step stays in place only while its cut has at least this % of its new members (few dragged members: little to save)
     int32_t stay_slack_pct = 6;       // free slots a run starts with beyond its widest (cut + new members), in % (granules that are only partly dead)
     int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):
                                       // more of them = longer runs before the slot space is full (memory: P grows)
