@@ -798,6 +798,15 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
             n = len(want)
             parts = [pl.compute(rows=r) for r in [(0, 5), (5, n // 3), (n // 3, n)]]
             _assert_equal(np.concatenate(parts, axis=0), want)
+            if not env and cap == 3000:
+                # the Float64 sweep on the same plan knows no slots (compact index arrays, its own buffers with the run's pitch)
+                pl.compute_device(storage64=True)
+                m64 = pl.result_to_host_f64()
+                pl.compute_device(storage64=True, kernel=1)
+                assert np.array_equal(m64, pl.result_to_host_f64())                  # row-staged == per-entry Float64 kernel
+                # (against the Float32-per-level result: one rounding per level apart; the exact recursion is exponential at this depth)
+                assert np.array_equal(m64, m64.T) and np.abs(m64 - want.astype(np.float64)).max() < 1e-6
+                _assert_equal(pl.compute(), want)
             pl.close()
     assert stays >= 100
     # a real genealogy (irregular generation gaps: members of one block leave at many different steps), wide levels forced
