@@ -514,6 +514,9 @@ def main():
                          "graph_replay_ms_per_step": replay_ms,
                          "graph_replay_frac": (pl.algorithmic_bytes * esz / 4.0 / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None},
         }
+        if out["config"]["in_place_steps"]:
+            out["roofline"]["frac_note"] = ("WIDE levels stay in place: the dragged x dragged block counts in the algorithmic bytes but is never "
+                                            "moved, so `frac` is not a bandwidth figure here (it can exceed 1); `real_traffic_frac` is")
         if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
         print(json.dumps(out), flush=True)
