@@ -11,6 +11,8 @@
 //   MODE 7: MODE 5 with an s_waitcnt vmcnt(0) in front of the LDS writes: the acknowledgement of the stage's row stores is waited
 //           for (what the product kernel does: its stores are conditional, so hipcc cannot count them out of the wait for the
 //           older prefetch loads; in MODE 5 the stores are unconditional and the wait is a counted vmcnt(N))
+//   MODE 8: MODE 5 with the row staged by ds_write_addtid_b32 (4 bytes per lane at M0 + offset + 4 * lane: 128 B/clk against the
+//           ~79 B/clk of ds_write_b128; the LDS image is then a permutation of the row, which the product would fold into its index words)
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off fast_stage_parts.hip -o fast_stage_parts
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,7 +41,7 @@ __global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float
     unsigned row = (((blockIdx.x >> 3) / share * 8 + (blockIdx.x & 7)) * 7919u) % n_rows;
     f4 pre[STG];
     float acc = 0.f;
-    constexpr bool kLoads = MODE >= 5, kStage = MODE >= 4;
+    constexpr bool kLoads = MODE >= 5, kStage = MODE >= 4, kAddTid = MODE == 8;
     if (kStage)
         for (int k = 0; k < STG; ++k) {
             const unsigned o = (tl + k * NT) * 4;
@@ -55,6 +57,16 @@ __global__ void __launch_bounds__(NT) stage(const float *__restrict__ psi, float
             for (int k = 0; k < STG; ++k) {
                 const unsigned o = (tl + k * NT) * 4;
                 if (k < STG - 1 || o < (unsigned)LD) {          // (only the last piece can lie past the row's end)
+                    if (kAddTid) {
+                        // byte address of (wave w, piece k, component c) = w * 1024 + k * 8192 + c * 256 (+ 4 * lane by the hardware):
+                        // M0 and the offset are 16 bits each, so the upper half of the row goes through a second M0 value
+                        const unsigned wv = __builtin_amdgcn_readfirstlane(tl >> 6);
+                        const unsigned m0v = wv * 1024u + (k < 8 ? 0u : 58116u);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(pre[k][c]), "s"(m0v),
+                                         "n"(k * 8192 + c * 256 - (k < 8 ? 0 : 58116)) : "memory");
+                    } else
                     *reinterpret_cast<f4 *>(sR + o) = pre[k];
                     if (kLoads) pre[k] = *reinterpret_cast<const f4 *>(psi + (size_t)row * LD + o);
                     else asm volatile("" : "+v"(pre[k]));
@@ -94,12 +106,12 @@ int main(int argc, char **argv)
     (void)hipMalloc(&psi, (size_t)n_rows * LD * 4); (void)hipMalloc(&out, (size_t)n_out_rows * OUTW * 4);
     (void)hipMemset(psi, 0, (size_t)n_rows * LD * 4);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    void (*ks[])(const float *, float *, unsigned, int, int, int) = {stage<0>, stage<1>, stage<2>, stage<3>, stage<4>, stage<5>, stage<6>, stage<7>};
+    void (*ks[])(const float *, float *, unsigned, int, int, int) = {stage<0>, stage<1>, stage<2>, stage<3>, stage<4>, stage<5>, stage<6>, stage<7>, stage<8>};
     const char *names[] = {"gathers only", "VALU only", "gathers + VALU", "+ row stores", "+ LDS staging, 2 barriers", "+ loads of the next row",
-                           "same, every load hits (row 0)", "MODE 5 + vmcnt(0) before the LDS writes"};
-    for (int m = 0; m < 8; ++m) {
+                           "same, every load hits (row 0)", "MODE 5 + vmcnt(0) before the LDS writes", "MODE 5, row staged by ds_write_addtid_b32"};
+    for (int m = 0; m < 9; ++m) {
         (void)hipFuncSetAttribute((const void *)ks[m], hipFuncAttributeMaxDynamicSharedMemorySize, LD * 4);
-        for (int share = 1; share <= (m == 5 || m == 7 ? 4 : 1); share *= 2) {
+        for (int share = 1; share <= (m == 5 || m == 7 || m == 8 ? 4 : 1); share *= 2) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 (void)hipEventRecord(a);
