@@ -1489,6 +1489,119 @@ level_full64_kernel(const double *__restrict__ psi, long long ld_prev, int n_pre
 #undef GENPHI_F64_FETCH
 }
 
+// Float64 storage, cuts whose rows fit in LDS one at a time (8 bytes x (n_prev + 1) <= 160 KB: up to 20,479 members): the SPLIT
+// kernels' shape in its simplest form.  A workgroup walks a contiguous piece of the row list (rows sharing the A source are
+// adjacent in a step's work order) for one chunk of 512 x 12 columns: row A is staged and its terms (a, b) of the chunk's columns
+// kept in registers for as long as the following rows share it; every row with a B source stages that row, gathers (c, d), combines
+// with the reference's grouping and stores.  The next row to stage is in flight into registers behind the gathers.  Same arguments
+// as level_full64_kernel.
+constexpr int kS64Cols = 12;      // columns per thread and chunk (registers: 7 per column + the 80 of the row in flight)
+constexpr int kS64Pre = 20;       // d2_t pieces per source row and thread: 20,480 / 2 / 512
+__global__ void __launch_bounds__(512)
+level_split64_kernel(const double *__restrict__ psi, long long ld_prev, int n_prev, double *__restrict__ out, long long ld,
+                     const int *__restrict__ srcA, const int *__restrict__ srcB, const int *__restrict__ ord,
+                     const int *__restrict__ rows, const int *__restrict__ out_rows, const int *__restrict__ colmap, int n_cols,
+                     int lds_row, int n_rows)
+{
+    extern __shared__ double srow[];
+    const int tid = threadIdx.x;
+    constexpr int nt = 512;
+    unsigned pkj[kS64Cols];
+    int oj[kS64Cols], jmv[kS64Cols];
+    double va[kS64Cols], vb[kS64Cols];
+    const int j0 = blockIdx.y * nt * kS64Cols;
+#pragma unroll
+    for (int k = 0; k < kS64Cols; ++k) {
+        const int j = j0 + tid + k * nt;
+        pkj[k] = 0; oj[k] = 0; jmv[k] = -1; va[k] = vb[k] = 0.0;
+        if (j < n_cols) {
+            const int jm = colmap ? colmap[j] : j;
+            jmv[k] = jm; pkj[k] = static_cast<unsigned>(srcA[jm]) | static_cast<unsigned>(srcB[jm]) << 16; oj[k] = ord[jm];
+        }
+    }
+    const int per = (n_rows + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int w0 = blockIdx.x * per, w1 = min(n_rows, w0 + per);
+    if (w0 >= w1) return;
+    const int nvec = lds_row >> 1;
+    d2_t pre[kS64Pre];
+    auto fetch = [&](int r) {
+        const d2_t *g2 = reinterpret_cast<const d2_t *>(psi + (long long)r * ld_prev);
+#pragma unroll
+        for (int k = 0; k < kS64Pre; ++k) pre[k] = g2[min(tid + k * nt, nvec - 1)];
+    };
+    auto to_lds = [&]() {
+        __syncthreads();                                  // the gathers from the previous row are done
+        d2_t *s2 = reinterpret_cast<d2_t *>(srow);
+#pragma unroll
+        for (int k = 0; k < kS64Pre; ++k) { const int q = tid + k * nt; if (q < nvec) s2[q] = pre[k]; }
+        __syncthreads();
+    };
+    // the row staged after (w, A just staged?): B of w, else the first A change / B source of the following rows; -1: none left
+    auto next_stage = [&](int w, bool after_a, int cur_a) -> int {
+        if (after_a) { const int b = srcB[rows ? rows[w] : w]; if (b != n_prev) return b; }
+        for (int v = w + 1; v < w1; ++v) {
+            const int i2 = rows ? rows[v] : v;
+            if (srcA[i2] != cur_a) return srcA[i2];
+            if (srcB[i2] != n_prev) return srcB[i2];
+        }
+        return -1;
+    };
+    int cur_a = -1;
+    {
+        const int i0 = rows ? rows[w0] : w0;
+        fetch(srcA[i0]);                                  // ("none" is the all-zero row: a parentless member's A)
+    }
+    for (int w = w0; w < w1; ++w) {
+        const int i = rows ? rows[w] : w;
+        const long long orow = out_rows ? out_rows[w] : i;
+        const int Ai = srcA[i], Bi = srcB[i], oi = ord[i];
+        const bool new_i = oi < 0;
+        const int ord_i = oi & kOrdMask;
+        unsigned z1 = 0;                                  // opaque zero (see level_full64_kernel)
+        asm volatile("" : "+s"(z1));
+        if (Ai != cur_a) {                                // stage A, keep its terms
+            to_lds();
+            cur_a = Ai;
+            const int nx = next_stage(w, true, cur_a);
+            if (nx >= 0) fetch(nx);
+#pragma unroll
+            for (int k = 0; k < kS64Cols; ++k) {
+                const unsigned pkz = pkj[k] ^ z1;
+                va[k] = srow[pkz & 0xffffu]; vb[k] = srow[pkz >> 16];
+            }
+        }
+        const bool has_b = Bi != n_prev;
+        if (has_b) {
+            to_lds();                                     // row B
+            const int nx = next_stage(w, false, cur_a);
+            if (nx >= 0) fetch(nx);
+        }
+        double *orowp = out + orow * ld;
+#pragma unroll
+        for (int k = 0; k < kS64Cols; ++k) {
+            const int j = j0 + tid + k * nt;
+            if (j >= ld) break;
+            double v = 0.0;
+            if (jmv[k] >= 0) {
+                const unsigned pkz = pkj[k] ^ z1;
+                const int ojz = oj[k] ^ static_cast<int>(z1);
+                if (jmv[k] == i && new_i) {
+                    v = 0.5 + 0.5 * (has_b ? srow[Ai] : 0.0);     // Psi[B][A] = Psi[A][B] (bit-symmetric levels)
+                } else {
+                    const double sc = (new_i ? 0.5 : 1.0) * (ojz < 0 ? 0.5 : 1.0);
+                    const double a = va[k], b = vb[k];
+                    const double c = has_b ? srow[pkz & 0xffffu] : 0.0, d = has_b ? srow[pkz >> 16] : 0.0;
+                    const bool i_hi = ord_i > (ojz & kOrdMask);
+                    const double x = i_hi ? b : c, y = i_hi ? c : b;
+                    v = ((a + x) + (y + d)) * sc;
+                }
+            }
+            orowp[j] = v;
+            if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 __global__ void half_identity64_kernel(double *m, long long ld, int n, const int *out_rows, int n_rows, const int *colmap)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2932,6 +3045,17 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
             hipLaunchKernelGGL(level_full64_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(chunks)), dim3(bs), lds64, p->stream, psi,
                                static_cast<long long>(st.ld_prev), static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), d.srcA, d.srcB,
                                d.ord, k_rows, k_orows, k_colmap, static_cast<int>(st.n), lds_row64, rows_n);
+        } else if (kernel != 1 && static_cast<size_t>(lds_row64) * sizeof(double) <= 160 * 1024 && rows_n > 0 && st.n_prev < 65535) {
+            // one Float64 source row fits (cuts up to 20,479 members): the one-row-at-a-time kernel, rows in the step's work order
+            // (same A source adjacent) where the step has one
+            const size_t lds1 = static_cast<size_t>(lds_row64) * sizeof(double);
+            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(level_split64_kernel), lds1));
+            const int chunks = static_cast<int>((st.ld + 512 * kS64Cols - 1) / (512 * kS64Cols));
+            const int *w_rows = last ? k_rows : ((st.mode != genphi::kModeWide && static_cast<int64_t>(st.work.size()) == st.n) ? d.work : static_cast<const int *>(nullptr));
+            const int grid_x = std::min(rows_n, std::max(1, p->n_cus / chunks) * 2);     // (two pieces per CU and chunk: the tail)
+            hipLaunchKernelGGL(level_split64_kernel, dim3(static_cast<unsigned>(grid_x), static_cast<unsigned>(chunks)), dim3(512), lds1, p->stream, psi,
+                               static_cast<long long>(st.ld_prev), static_cast<int>(st.n_prev), out, static_cast<long long>(st.ld), d.srcA, d.srcB,
+                               d.ord, w_rows, k_orows, k_colmap, static_cast<int>(st.n), lds_row64, rows_n);
         } else {
             dim3 grid(static_cast<unsigned>(rows_n), static_cast<unsigned>((st.ld + 255) / 256));
             hipLaunchKernelGGL(level_naive64_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(st.ld_prev),

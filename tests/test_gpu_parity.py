@@ -921,6 +921,21 @@ def test_float64_sweep_kernels(gen, oracle, monkeypatch):
     sm = [(int(x), int(y)) for x, y in zip(rng.integers(0, n_pro, 10), rng.integers(0, n_pro, 10))] + [(10500, 10999), (10999, 10999), (5, 5)]
     got = both(ind, fa, mo, pro, sm)
     assert got.shape == (n_pro, n_pro) and np.array_equal(got[:300, 10240:], got[10240:, :300].T)
+    # (e) cuts between 10,240 and 20,479 members: one Float64 row at a time in LDS (level_split64_kernel), genea140's widest levels
+    ped = gen.genealogy(gen.genea140)
+    op = oracle.Pedigree.from_file(gen.genea140)
+    pro = gen.pro(ped)
+    pl = gen.plan(ped, pro)
+    assert max(pl.levels()[0]) > 10240
+    pl.compute_device(storage64=True)
+    a = pl.result_to_host_f64().copy()
+    pl.compute_device(storage64=True, kernel=1)
+    assert np.array_equal(a, pl.result_to_host_f64()) and np.array_equal(a, a.T)
+    for i, j in [(0, 0), (3, 77), (139, 12), (50, 51)]:
+        assert a[i, j] == op.phi_pair(int(pro[i]), int(pro[j])), (i, j)
+    pl.compute_device(storage64=True, rows=(20, 61))
+    assert np.array_equal(pl.result_to_host_f64(), a[20:61])
+    pl.close()
     # (d) tiny cuts: 64-thread workgroups (geneaJi, every individual a proband of its own sweep)
     ped = gen.genealogy(gen.geneaJi)
     op = oracle.Pedigree.from_file(gen.geneaJi)
