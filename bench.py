@@ -37,6 +37,9 @@ WORKLOADS = {
     # cut dragged along, B = 1.45 TB): the WIDE block-assembly levels.  Not a BASELINE.json config.
     "cfg4o": (1_000_000, 100_000, 30, 5),
     "cfg3": (100_000, 10_000, 20),
+    # cfg3 exactly as SURVEY.md 8(d) words it: 5 % of the parents come from generation g-2 "to exercise the dragged
+    # path" (cuts to 20,540 members, up to 91 % of a cut dragged along, B = 26.25 GB, 1.66e9 pair evaluations).
+    "cfg3s": (100_000, 10_000, 20, 50),
     "cfg2": "genea140",
     "cfg5": "deep_inbred",
 }
@@ -337,10 +340,11 @@ def main():
     if world > 1 or args.exchange:
         from genlib_jl_amd import distributed as gdist
         probe = gen.plan(ped, pro)
-        cut_sizes = probe.levels()[0]
+        cut_sizes, both_counts = probe.levels()
         probe.close()
         # the decision is collective (MIN over the ranks): every rank must take the same path
-        fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0], dist=dist, device=torch.device("cuda", local_rank))
+        fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0], dist=dist, device=torch.device("cuda", local_rank),
+                                           both_counts=both_counts)
         if args.exchange or os.environ.get("GENPHI_FORCE_EXCHANGE") == "1" or not fits:
             return run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits)
     t_plan = time.perf_counter()

@@ -1865,6 +1865,8 @@ struct Tuning {
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
     int stay_min_ratio_pct = -1;   // GENPHI_STAY_MIN_RATIO_PCT tuning: a step stays in place while cut >= this % of its new members (default 200)
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
+    int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour)
+    int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
     bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
     bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
     bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
@@ -1907,6 +1909,8 @@ static Tuning tuning_from_env()
     t.stay_col_fastest = geti("GENPHI_STAY_COL_FASTEST", 0) != 0;
     t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.stay_min_ratio_pct = geti("GENPHI_STAY_MIN_RATIO_PCT", -1);
+    t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
+    t.stay_narrow_min = geti("GENPHI_STAY_NARROW_MIN", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -2129,8 +2133,10 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.stay_slack_pct >= 0) p->popt.stay_slack_pct = p->tun.stay_slack_pct;
     if (p->tun.stay_min_ratio_pct >= 0) p->popt.stay_min_ratio_pct = p->tun.stay_min_ratio_pct;
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
+    if (p->tun.stay_narrow >= 0) p->popt.stay_narrow = p->tun.stay_narrow != 0;
+    if (p->tun.stay_narrow_min >= 0) p->popt.stay_narrow_min = p->tun.stay_narrow_min;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
-    if (p->tun.stay_mem_pct > 0) p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0;
+    if (p->tun.stay_mem_pct > 0) { p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0; p->popt.stay_mem_floor_bytes = 0.0; }   // (an explicit share is taken literally)
     std::string err;
     int rc;
     try {

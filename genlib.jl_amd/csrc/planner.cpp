@@ -381,15 +381,80 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         int64_t run = 0;
         for (int32_t c = 0; c < L; ++c) { run += diff[c]; size_of[c] = run; }
     }
-    // Cuts produced by a WIDE step may be kept in place (LevelStep::stay): their new members are then ordered by the cut after
-    // which they leave, earliest first (rank order inside a class), so that the slots of a block die from its start.
+    // Block assembly (kModeWide) per cut: blk[c] = the step that produces cut c assembles its level block by block.  Always so when a
+    // source row does not fit in LDS; beyond that, steps of narrower cuts are switched to it when a run of them can be kept IN PLACE
+    // (LevelStep::stay) and the bytes saved -- the dragged x dragged block is most of a level of overlapping generations, real
+    // genealogies: src/compute.jl:108-110 -- outweigh the extra passes (the cost model below, in matrix entries moved).
     const bool stay_on = !opt.indices_only && !opt.no_stay;
-    auto wide_step = [&](int32_t c) { return c >= 1 && c < L && mode_for(size_of[c - 1], opt) == kModeWide; };   // the step that produces cut c
+    std::vector<char> blk(L, 0);
+    for (int32_t c = 1; c < L; ++c) blk[c] = mode_for(size_of[c - 1], opt) == kModeWide ? 1 : 0;
+    std::vector<int64_t> n_par_of(L, 0);                                 // distinct parents of the new members of cut c
+    {
+        std::vector<int32_t> seen(n_ind > 0 ? n_ind : 1, -1);
+        for (int32_t c = 1; c < L && stay_on; ++c) {
+            int64_t np = 0;
+            for (int32_t x : new_of[c]) {
+                if (fa[x] >= 0 && seen[fa[x]] != c) { seen[fa[x]] = c; ++np; }
+                if (mo[x] >= 0 && seen[mo[x]] != c) { seen[mo[x]] = c; ++np; }
+            }
+            n_par_of[c] = np;
+        }
+    }
+    // (the new x new block of the step itself and of the step that reads its cut must have a row kernel: the per-entry
+    // fallback knows no slots; cut 1 is out because cut 0 = 1/2 I is normally never materialised)
+    auto nn_ok = [&](int32_t c) { return new_of[c].empty() || mode_for(n_par_of[c], opt) != kModeWide; };
+    // want[c]: cut c may be produced in place -- worth it while the dragged x dragged block that is not copied outweighs the new
+    // rows (late levels of shrinking cuts have few dragged members, and reading a cut by slot costs the next step its faster
+    // route).  run_end[c] > 0: a run of in-place cuts c .. run_end[c] is planned (the slot search below may still end it early).
+    std::vector<char> want(L, 0);
+    std::vector<int32_t> run_end(L, 0);
+    if (stay_on) {
+        auto nnew = [&](int32_t c) { return static_cast<double>(new_of[c].size()); };
+        auto ndrag = [&](int32_t c) { return static_cast<double>(size_of[c]) - nnew(c); };
+        // entries moved by the step that produces cut c: as a row-kernel level (every row staged and written whole) ...
+        auto cost_rows = [&](int32_t c) {
+            const double np = static_cast<double>(size_of[c - 1]), n = static_cast<double>(size_of[c]);
+            return (ndrag(c) + 1.5 * nnew(c)) * np + n * n;
+        };
+        // ... the blocks that involve new members, common to both forms of block assembly (Psi_P, the new x new sub-step) ...
+        auto cost_nn = [&](int32_t c) {
+            const double q = static_cast<double>(n_par_of[c]);
+            return 2.0 * q * q + 1.5 * nnew(c) * q + nnew(c) * nnew(c);
+        };
+        // ... assembled compactly (every row re-written at the dragged columns, the transposed block) ...
+        auto cost_blk = [&](int32_t c) {
+            const double np = static_cast<double>(size_of[c - 1]), n = static_cast<double>(size_of[c]);
+            return cost_nn(c) + (ndrag(c) + 2.0 * nnew(c)) * np + n * ndrag(c) + 2.0 * nnew(c) * ndrag(c);
+        };
+        // ... in place (only the new rows and columns move; the new x new block may go through the scatter buffer)
+        auto cost_stay = [&](int32_t c) { return cost_nn(c) + nnew(c) * nnew(c) + 3.5 * nnew(c) * ndrag(c); };
+        for (int32_t c = 2; c + 1 < L; ++c) {
+            const bool by_width = blk[c] && blk[c + 1];                  // both steps assemble blocks anyway
+            const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min && c + 2 < L &&      // (the reader is never the proband step)
+                                cost_stay(c) < (blk[c] ? cost_blk(c) : cost_rows(c));
+            want[c] = (by_width || narrow) && 100 * size_of[c] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
+                      size_of[c] > static_cast<int64_t>(new_of[c].size()) && nn_ok(c) && nn_ok(c + 1);
+        }
+        for (int32_t c = 2; c + 1 < L;) {
+            if (!want[c]) { ++c; continue; }
+            int32_t e = c;
+            while (e + 2 < L && want[e + 1]) ++e;
+            // the step that reads the run's last cut by slot assembles blocks: a loss when it would have been a row-kernel level
+            double gain = blk[e + 1] ? 0.0 : cost_rows(e + 1) - cost_blk(e + 1);
+            for (int32_t cc = c; cc <= e; ++cc) gain += (blk[cc] ? cost_blk(cc) : cost_rows(cc)) - cost_stay(cc);
+            bool all_wide = blk[e + 1] != 0;
+            for (int32_t cc = c; cc <= e; ++cc) all_wide = all_wide && blk[cc];
+            if (all_wide || gain > 0.0) run_end[c] = e;
+            c = e + 1;
+        }
+    }
+    // Cuts produced in place: their new members are ordered by the cut after which they leave, earliest first (rank order inside
+    // a class), so that the slots of a block die from its start.
     if (stay_on) {
         std::vector<int32_t> key(n_ind > 0 ? n_ind : 1, 0), tmp, cnt;
-        bool any_run = false;                                            // two WIDE steps in a row somewhere?
-        for (int32_t c = 2; c + 1 < L && !any_run; ++c) any_run = wide_step(c) && wide_step(c + 1);
-        // (every block of such a plan, the cuts above the WIDE region too: the cut a run starts from is made of them)
+        bool any_run = false;
+        for (int32_t c = 2; c + 1 < L && !any_run; ++c) any_run = run_end[c] > 0;
+        // (every block of such a plan, the cuts above the region too: the cut a run starts from is made of them)
         for (int32_t c = 0; c + 1 < L && any_run; ++c) {
             if (new_of[c].size() < 2) continue;
             for (int32_t x : new_of[c]) key[x] = L - 1 - tfirst[x];      // the last cut x is in: early leavers first (the slots are
@@ -426,37 +491,16 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     if (stay_on) {
         auto pad64 = [](int64_t v) { return (v + 63) / 64 * 64; };
         std::vector<int32_t> slot_of(n_ind > 0 ? n_ind : 1, -1);
-        std::vector<int32_t> seen(n_ind > 0 ? n_ind : 1, -1);
-        int32_t call = 0;
-        auto n_parents = [&](int32_t c) {                            // distinct parents of the new members of cut c
-            int64_t np = 0;
-            ++call;
-            for (int32_t x : new_of[c]) {
-                if (fa[x] >= 0 && seen[fa[x]] != call) { seen[fa[x]] = call; ++np; }
-                if (mo[x] >= 0 && seen[mo[x]] != call) { seen[mo[x]] = call; ++np; }
-            }
-            return np;
-        };
-        // (the new x new block of the step itself and of the step that reads its cut must have a row kernel: the per-entry
-        // fallback knows no slots; cut 1 is out because cut 0 = 1/2 I is normally never materialised)
-        auto nn_ok = [&](int32_t c) { return new_of[c].empty() || mode_for(n_parents(c), opt) != kModeWide; };
-        auto can = [&](int32_t c) {
-            // (worth it while the dragged x dragged block that is not copied outweighs the new rows: late levels of shrinking cuts
-            // have few dragged members, and reading a cut by slot costs the next step its faster route)
-            return c >= 2 && wide_step(c) && c + 1 < L && wide_step(c + 1) && 100 * static_cast<int64_t>(cut[c].size()) >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
-                   cut[c].size() > new_of[c].size() && nn_ok(c) && nn_ok(c + 1);
-        };
         std::vector<int32_t> last_at;                                // per slot: last cut of its occupant (-1: free)
         for (int32_t c = 1; c + 1 < L;) {
-            if (!can(c)) { ++c; continue; }
-            int32_t e = c;
-            while (e + 2 < L && can(e + 1)) ++e;
-            int64_t P = 0, blk = 0;
+            if (run_end[c] <= 0) { ++c; continue; }
+            const int32_t e = run_end[c];
+            int64_t P = 0, blk_max = 0;
             for (int32_t cc = c; cc <= e; ++cc) {
                 P = std::max(P, size_of[cc - 1] + pad64(static_cast<int64_t>(new_of[cc].size())));
-                blk = std::max(blk, pad64(static_cast<int64_t>(new_of[cc].size())));
+                blk_max = std::max(blk_max, pad64(static_cast<int64_t>(new_of[cc].size())));
             }
-            P = pad64(P + P * std::max(0, opt.stay_slack_pct) / 100 + 64) + std::max(0, opt.stay_headroom) * blk;      // slack for granules that are only partly dead
+            P = pad64(P + P * std::max(0, opt.stay_slack_pct) / 100 + 64) + std::max(0, opt.stay_headroom) * blk_max;      // slack for granules that are only partly dead
             if (P > opt.stay_max_slots || P >= (int64_t(1) << 30)) { c = e + 1; continue; }
             // the entry cut c - 1 sits at slots [0, n) of the matrix (written compactly, with pitch P, by its own step)
             const std::vector<int32_t> &ent = cut[c - 1];
@@ -528,16 +572,21 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             }
             if (done >= c) {
                 for (int32_t cc = c - 1; cc <= done; ++cc) { slotP[cc] = static_cast<int32_t>(P); plan.ld[cc] = P; }
+                for (int32_t cc = c; cc <= done + 1; ++cc) blk[cc] = 1;      // the run's steps and the step that leaves it assemble blocks
                 sources(done + 1);                                   // the step that leaves the run reads by slot
+                // (a run the slot space ended early: what is left of it may start again behind the compacting step)
+                if (done + 2 <= e && done + 2 + 1 < L) run_end[done + 2] = e;
                 c = done + 2;
             } else {
                 slots_c[c - 1].clear();
+                if (c + 1 <= e) run_end[c + 1] = e;
                 ++c;
             }
         }
     }
     // Memory: the two level buffers with in-place runs against plain alternation.  Usually less (one P x P matrix + the entry cut
-    // instead of two matrices of the widest cuts); several runs with large P in both buffers can need more -- then not in place.
+    // instead of two matrices of the widest cuts); several runs with large P in both buffers can need more -- then not in place
+    // (unless it is small change anyway: narrow cuts, stay_mem_floor_bytes).
     if (stay_on) {
         double need_s[2] = {0, 0}, need_p[2] = {0, 0};
         int b = 0;
@@ -549,13 +598,13 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             need_s[b] = std::max(need_s[b], rows * static_cast<double>(plan.ld[c]));
             need_p[c & 1] = std::max(need_p[c & 1], (static_cast<double>(plan.cut_sizes[c]) + 1.0) * static_cast<double>(pitch_for(plan.cut_sizes[c])));
         }
-        if (any && need_s[0] + need_s[1] > opt.stay_mem_ratio * (need_p[0] + need_p[1])) {
+        if (any && need_s[0] + need_s[1] > opt.stay_mem_ratio * (need_p[0] + need_p[1]) && 4.0 * (need_s[0] + need_s[1]) > opt.stay_mem_floor_bytes) {
             PlanOptions o2 = opt;
             o2.no_stay = true;
             return build_plan(n_ind, ind, father, mother, n_pro, pro_ids, o2, plan, err);
         }
     }
-    const bool last_wide = L >= 2 && mode_for(plan.cut_sizes[L - 2], opt) == kModeWide;
+    const bool last_wide = L >= 2 && blk[L - 1];
     if (!last_wide) {
         cut[L - 1] = plan.final_members;
     } else {
@@ -598,7 +647,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         st.ld_prev = plan.ld[c - 1]; st.ld = plan.ld[c];
         // (the entry cut of an in-place run has the run's pitch P but is written compactly: no zero padding beyond its own width)
         st.width = (slotP[c] > 0 && !stay_c[c]) ? pitch_for(n) : st.ld;
-        st.mode = mode_for(n_prev, opt);
+        st.mode = blk[c] ? kModeWide : mode_for(n_prev, opt);
         st.srcA.resize(n); st.srcB.resize(n); st.ord.resize(n);
         const int32_t none = static_cast<int32_t>(n_prev);
         int64_t dragged = 0;

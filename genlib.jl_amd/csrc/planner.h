@@ -108,8 +108,12 @@ struct PlanOptions {
     bool stay_scatter = false;        // in-place steps never write their new x new block in place (A/B and test hook: always through the compact buffer)
     int64_t stay_max_slots = 200000;  // largest slot capacity P of a run (a P x P Float32 matrix: 160 GB)
     double stay_mem_ratio = 1.2;      // in-place runs are dropped when the two level buffers would need more than this x plain alternation
+    double stay_mem_floor_bytes = 4294967296.0;   // ... and more than this many bytes (4 GiB: the slot matrices of narrow cuts are small change)
     int32_t stay_min_ratio_pct = 200; // a step stays in place only while its cut has at least this % of its new members (few dragged members: little to save)
     int32_t stay_slack_pct = 6;       // free slots a run starts with beyond its widest (cut + new members), in % (granules that are only partly dead)
+    bool stay_narrow = true;          // cuts whose rows fit in LDS (FULL / SPLIT widths) may stay in place too: their steps are switched to block
+                                      // assembly when the cost model says the dragged x dragged copy that is saved outweighs the extra passes
+    int64_t stay_narrow_min = 2048;   // ... from this width of the source cut on (narrower levels are bound by their launches, not their bytes)
     int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):
                                       // more of them = longer runs before the slot space is full (memory: P grows)
 };

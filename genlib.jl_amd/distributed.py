@@ -105,13 +105,14 @@ def phi_panels(pedigree, probandIDs, dist=None, device=None, stats=None):
         pl.close()
 
 
-def replicated_bytes(cut_sizes, wide_last=False):
+def replicated_bytes(cut_sizes, wide_last=False, both_counts=None):
     """Device bytes of the replicated path for these cuts, as genphi_compute_device allocates them
     (csrc/genphi_hip.hip: upload_plan / ensure_level_buffers / the result): two ping-pong buffers sized by
     the largest EVEN and the largest ODD intermediate cut (not by the largest consecutive pair), the
     N x pitch(N) result, a second copy of the last level when its step is WIDE (proband-order delivery),
     the tail padding of each buffer, and ~30 bytes of index arrays per member per level.  The compacted
-    parent matrix of WIDE steps is bounded by the largest intermediate level."""
+    parent matrix of block-assembly steps is bounded by the largest intermediate level.  both_counts (members
+    dragged along per step): all zero means no step assembles blocks below the LDS width and nothing stays in place."""
     pitch = lambda n: (n + 1 + 63) // 64 * 64          # noqa: E731
     tail = 64 * 1024
     need = [0, 0]
@@ -121,21 +122,23 @@ def replicated_bytes(cut_sizes, wide_last=False):
     total = need[0] + need[1] + n_last * pitch(n_last)
     if wide_last:
         total += (n_last + 1) * pitch(n_last) + tail
-    if max(cut_sizes[:-1], default=0) > 36863:         # WIDE steps (a source row does not fit in LDS): psi_p
+    dragged = both_counts is None or any(b > 0 for b in both_counts)
+    if max(cut_sizes[:-1], default=0) > 36863 or dragged:    # block-assembly steps (WIDE, or a run kept in place): psi_p, the scatter buffer
         total += max(need)
-        # runs of WIDE steps may stay in place: ONE slot matrix instead of two ping-pong ones -- the planner drops
-        # the runs when that needs more than 1.2 x the plain buffers (PlanOptions::stay_mem_ratio), so that is the bound
-        total += (need[0] + need[1]) // 5
+        # runs of steps may stay in place: ONE slot matrix instead of two ping-pong ones -- the planner drops the runs
+        # when that needs more than 1.2 x the plain buffers and more than 4 GiB (PlanOptions::stay_mem_ratio,
+        # stay_mem_floor_bytes), so that is the bound
+        total += max((need[0] + need[1]) // 5, (1 << 30) - (need[0] + need[1]))
     return 4 * total + 30 * sum(cut_sizes)
 
 
-def replicated_levels_fit(cut_sizes, free_bytes, dist=None, device=None):
+def replicated_levels_fit(cut_sizes, free_bytes, dist=None, device=None, both_counts=None):
     """The size test of SURVEY.md 8(e): do the replicated level matrices plus the result fit one GPU?
     With `dist` the answer is made COLLECTIVE (MIN over the ranks): ranks see different amounts of free
     memory, and a rank that went down the exchange path while its peers went down the replicated one
     would wait in a collective nobody else enters."""
     wide_last = len(cut_sizes) >= 2 and cut_sizes[-2] > 36863      # the last step reads rows of the cut before it
-    fits = replicated_bytes(cut_sizes, wide_last=wide_last) <= 0.92 * free_bytes
+    fits = replicated_bytes(cut_sizes, wide_last=wide_last, both_counts=both_counts) <= 0.92 * free_bytes
     if dist is not None and dist.get_world_size() > 1:
         import torch
         t = torch.tensor([1 if fits else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")

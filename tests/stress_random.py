@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
-         "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS"]
+         "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT"]
 
 
 def make_case(case):
@@ -63,6 +64,13 @@ def make_case(case):
         env["GENPHI_STAY_SCATTER"] = "1"                                          # the new x new block always through the compact buffer
     if r.random() < 0.8:
         env["GENPHI_STAY_MEM_PCT"] = "100000"                                     # (small cuts: the slot matrix is many times the plain buffers)
+    # in-place runs at FULL / SPLIT widths (round 4): the cost model decides per run; small pedigrees need the width floor lowered
+    if r.random() < 0.65:
+        env["GENPHI_STAY_NARROW_MIN"] = str(int(r.choice([0, 16, 64, 200])))
+    elif r.random() < 0.3:
+        env["GENPHI_STAY_NARROW"] = "0"
+    if r.random() < 0.3:
+        env["GENPHI_STAY_MIN_RATIO_PCT"] = str(int(r.choice([110, 150, 300])))       # in place with few dragged members too / only with many
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env
 
 
@@ -124,7 +132,7 @@ def main():
             print(f"FAIL case={case} gens={n_gen} n_ind={n_ind} n_pro={n_pro} skip={skip} env={env} -> {what}", flush=True)
         if n_cases % 20 == 0:
             print(f"... {n_cases} cases, {n_fail} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"stress: {n_cases} cases ({n_stay} in-place WIDE steps among them), {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
+    print(f"stress: {n_cases} cases ({n_stay} in-place steps among them), {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
     return 1 if n_fail else 0
 
 

@@ -43,16 +43,20 @@ def test_replicated_memory_model_matches_the_allocations():
     from genlib_jl_amd import distributed as gdist
     pitch = lambda n: (n + 1 + 63) // 64 * 64      # noqa: E731
     cuts = [10, 5000, 200, 7000, 3000, 9000, 100, 4000]           # the two largest intermediate cuts are not consecutive
-    b = gdist.replicated_bytes(cuts)
+    none = [0] * (len(cuts) - 1)                                  # no member dragged along: no block assembly, nothing in place
+    b = gdist.replicated_bytes(cuts, both_counts=none)
     even, odd = max(cuts[0:-1:2]), max(cuts[1:-1:2])
     want = 4 * ((even + 1) * pitch(even) + (odd + 1) * pitch(odd) + 4000 * pitch(4000))
     assert want <= b <= want + 4 * 2 * 65536 + 30 * sum(cuts) + 1024
     pair = max(4 * ((a + 1) * pitch(a) + (c + 1) * pitch(c)) for a, c in zip(cuts[:-1], cuts[1:]))
     assert b > pair                                                # the old pairwise model under-estimated
-    assert gdist.replicated_levels_fit(cuts, b / 0.92 + 1) and not gdist.replicated_levels_fit(cuts, b / 0.92 - 1e6)
+    assert gdist.replicated_levels_fit(cuts, b / 0.92 + 1, both_counts=none) and not gdist.replicated_levels_fit(cuts, b / 0.92 - 1e6, both_counts=none)
+    # members dragged along (or unknown): the parent matrix of block-assembly steps and the slot matrix of in-place runs on top
+    assert 4 * (1 << 30) <= gdist.replicated_bytes(cuts) <= b + 4 * (1 << 30) + 4 * (9001 * pitch(9000) + 65536)
     # cfg4: 3.8 GB + 2.4 GB of level matrices + the 40 GB result
     cfg4 = [24301] * 24 + [24650, 25190, 26502, 30976, 100000]
-    assert 45e9 < gdist.replicated_bytes(cfg4) < 48e9
+    assert 45e9 < gdist.replicated_bytes(cfg4, both_counts=[0] * 28) < 48e9
+    assert gdist.replicated_bytes(cfg4) < 55e9
 
 
 def test_two_rank_gloo_dry_run():
