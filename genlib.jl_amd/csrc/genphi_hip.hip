@@ -1223,10 +1223,13 @@ slots_scatter_kernel(const float *__restrict__ t, long long ld_t, int n_new, con
     if (threadIdx.x == 0 && cert_out) cert_out[row] = cert_t[r];
 }
 // certificate words of the new members' slots := 0 (before the step flags them)
-__global__ void __launch_bounds__(256) slots_clear_kernel(int *__restrict__ words, const int *__restrict__ blk_slot, int n_gran)
+// (and, in the same launch, the step's scratch certificate words -- those of Psi_P's rows and of the scatter buffer's: `extra`)
+__global__ void __launch_bounds__(256) slots_clear_kernel(int *__restrict__ words, const int *__restrict__ blk_slot, int n_gran,
+                                                          int *__restrict__ extra, int n_extra)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k < n_gran * 64) words[blk_slot[k >> 6] + (k & 63)] = 0;
+    for (int q = k; q < n_extra; q += gridDim.x * 256) extra[q] = 0;
 }
 // dragged x new = (new x dragged)^T in place: source row r of the block = new member r (row slot(r) of m), destination
 // column slot(r), for the columns / destination rows [c_lo, c_lo + cols).  64 x 64 tiles: a tile row is one granule.
@@ -1271,14 +1274,16 @@ transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict_
 constexpr int kFT = 256;
 __global__ void __launch_bounds__(256)
 rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ rowdesc, int n_new, const int *__restrict__ blk_slot,
-                  int c_lo, int cols, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest)
+                  const int2 *__restrict__ tiles, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest)
 {
     extern __shared__ float tile_dyn[];                          // [64][kFT + 1]
     float (*tile)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(tile_dyn);
     // (gran_fastest: consecutive workgroups take the SAME columns of different granules -- a parent's row piece is then read by
     // its children's workgroups close in time)
     const int g = gran_fastest ? blockIdx.x : blockIdx.y, ct = gran_fastest ? blockIdx.y : blockIdx.x;
-    const int c0 = c_lo + ct * kFT, c_hi = c_lo + cols;
+    // the column tiles of ALL slot ranges that hold dragged members in one launch: tiles[ct] = (first column, end of its range)
+    const int2 tl = tiles[ct];
+    const int c0 = tl.x, c_hi = tl.y, c_lo = tl.x;
     const int base = blk_slot[g], rows_here = min(64, n_new - g * 64);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = c0 + lane * 4;                                // this lane's four columns (ranges are multiples of 64 columns)
@@ -1865,7 +1870,8 @@ struct Tuning {
     int stay_mem_pct = 0;          // GENPHI_STAY_MEM_PCT     test: in-place runs may need this % of the plain buffers' memory (default 120)
     int stay_min_ratio_pct = -1;   // GENPHI_STAY_MIN_RATIO_PCT tuning: a step stays in place while cut >= this % of its new members (default 200)
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
-    int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour)
+    int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour); 2 = in place wherever the ratio test allows, whatever the cost model says
+    int stay_family = -1;          // GENPHI_STAY_FAMILY      A/B: 0 = new members of a leaving class in rank order instead of by family
     int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
     bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
     bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
@@ -1911,6 +1917,7 @@ static Tuning tuning_from_env()
     t.stay_min_ratio_pct = geti("GENPHI_STAY_MIN_RATIO_PCT", -1);
     t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
     t.stay_narrow_min = geti("GENPHI_STAY_NARROW_MIN", -1);
+    t.stay_family = geti("GENPHI_STAY_FAMILY", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
     t.full_bs = geti("GENPHI_FULL_BS", 0);
@@ -1963,6 +1970,8 @@ struct DeviceStep {
     int *idx = nullptr;        // source column of every dragged member (= srcA; the sources' SLOTS when the source cut is stored by slot:
                                // then rowdesc / pardesc / parents hold slots too, see LevelStep::src_slots)
     int *blk_slot = nullptr;   // (in-place steps) first slot of every granule of 64 new members
+    int2 *tiles = nullptr;     // (in-place steps) the kFT-column tiles of the slot ranges that hold dragged members: (first column, end of the range)
+    int n_tiles = 0;
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -2090,7 +2099,7 @@ static void free_device(genphi_plan *p)
     p->shard_groups = DeviceGroups(); p->shard_blob_bytes = 0; p->cert_off.clear(); p->cert_words = 0;
     release(p->d_queues); release(p->d_small); release(p->sh_blob); release(p->scratch);
     release(p->buf[0]); release(p->buf[1]); release(p->result); release(p->final_tmp);
-    release(p->psi_p); release(p->d_cert_p); release(p->nn_tmp); release(p->d_cert_t);
+    release(p->psi_p); release(p->d_cert_p); release(p->nn_tmp); p->d_cert_t = nullptr;      // (d_cert_t lives inside d_cert_p's array)
     release(p->buf64[0]); release(p->buf64[1]); release(p->result64); release(p->d_perm_rows);
     p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
     p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
@@ -2133,8 +2142,9 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.stay_slack_pct >= 0) p->popt.stay_slack_pct = p->tun.stay_slack_pct;
     if (p->tun.stay_min_ratio_pct >= 0) p->popt.stay_min_ratio_pct = p->tun.stay_min_ratio_pct;
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
-    if (p->tun.stay_narrow >= 0) p->popt.stay_narrow = p->tun.stay_narrow != 0;
+    if (p->tun.stay_narrow >= 0) { p->popt.stay_narrow = p->tun.stay_narrow != 0; p->popt.stay_narrow_force = p->tun.stay_narrow == 2; }
     if (p->tun.stay_narrow_min >= 0) p->popt.stay_narrow_min = p->tun.stay_narrow_min;
+    if (p->tun.stay_family >= 0) p->popt.stay_family_order = p->tun.stay_family != 0;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     if (p->tun.stay_mem_pct > 0) { p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0; p->popt.stay_mem_floor_bytes = 0.0; }   // (an explicit share is taken literally)
     std::string err;
@@ -2276,7 +2286,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +
-                     al(s.blk_slot.size() * sizeof(int));
+                     al(s.blk_slot.size() * sizeof(int)) + al((s.live_ranges.size() / 2 + static_cast<size_t>(s.stay ? s.P : 0) / 256 + 1) * sizeof(int2));
     }
     total += al(pl.final_perm.size() * sizeof(int));
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
@@ -2323,6 +2333,13 @@ static int upload_plan_impl(genphi_plan *p, int device)
             d.newrows = reinterpret_cast<int *>(put(nr.data(), nr.size() * sizeof(int)));
             d.idx = reinterpret_cast<int *>(put(sA, s.n_dragged * sizeof(int)));
             d.blk_slot = reinterpret_cast<int *>(put(s.blk_slot.data(), s.blk_slot.size() * sizeof(int)));
+            {   // column tiles of rows_avg_t_kernel over all live ranges (one launch per step)
+                std::vector<int2> tl;
+                for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2)
+                    for (int c0 = s.live_ranges[h]; c0 < s.live_ranges[h + 1]; c0 += kFT) tl.push_back(make_int2(c0, s.live_ranges[h + 1]));
+                d.n_tiles = static_cast<int>(tl.size());
+                d.tiles = reinterpret_cast<int2 *>(put(tl.data(), tl.size() * sizeof(int2)));
+            }
             // drag_rows_kernel: parents inside the source window of each chunk of 8192 dragged columns
             const int64_t chunk = 8192, nch = (s.n_dragged + chunk - 1) / chunk;
             std::vector<int> ps(nch + 1, 0);
@@ -2411,13 +2428,15 @@ static int ensure_level_buffers_impl(genphi_plan *p)
         if (need_t) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->nn_tmp), (need_t * need_t + kTailPadFloats) * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->nn_tmp, 0, (need_t * need_t + kTailPadFloats) * sizeof(float), p->stream));
-            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_t), (need_t + 1) * sizeof(int)));
         }
         if (need_p) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->psi_p, 0, need_p * sizeof(float), p->stream));
-            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_p), need_c * sizeof(int)));
-            p->cert_p_words = need_c;
+        }
+        if (need_p || need_t) {                                    // (one array: an in-place step clears both in one launch)
+            HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_p), (need_c + need_t + 1) * sizeof(int)));
+            p->d_cert_t = p->d_cert_p + need_c;
+            p->cert_p_words = need_c + need_t + 1;
         }
     }
     p->level_bufs_ready = true;
@@ -2830,9 +2849,10 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     }
     if (stay && n_new == 0) return GENPHI_OK;                   // the cut only lost members: nothing moves
     const int n_gran = static_cast<int>(s.blk_slot.size());
-    if (stay) {                                                 // the new members' certificate words
-        hipLaunchKernelGGL(slots_clear_kernel, dim3(static_cast<unsigned>((n_gran * 64 + 255) / 256)), dim3(256), 0, p->stream, cert_out, d.blk_slot, n_gran);
-        HIP_TRY(hipMemsetAsync(p->d_cert_t, 0, (static_cast<size_t>(s.npad) + 1) * sizeof(int), p->stream));
+    if (stay) {                                                 // the new members' certificate words; those of Psi_P's rows and of the scatter buffer's
+        hipLaunchKernelGGL(slots_clear_kernel, dim3(static_cast<unsigned>((n_gran * 64 + 255) / 256)), dim3(256), 0, p->stream, cert_out, d.blk_slot, n_gran,
+                           p->d_cert_p, static_cast<int>(p->cert_p_words));
+        HIP_TRY(hipGetLastError());
     }
     const bool nn_naive = s.nn_naive || s.nn.empty();
     if (n_new > 0 && !nn_naive) {
@@ -2840,7 +2860,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         const LevelStep &nn = s.nn[0];
         const DeviceStep &dn = p->nn_dsteps[d.nn];
         const int n_par = static_cast<int>(nn.n_prev);
-        HIP_TRY(hipMemsetAsync(p->d_cert_p, 0, (static_cast<size_t>(n_par) + 1) * sizeof(int), p->stream));
+        if (!stay) HIP_TRY(hipMemsetAsync(p->d_cert_p, 0, (static_cast<size_t>(n_par) + 1) * sizeof(int), p->stream));
         if (n_par > 0) {
             dim3 grid(static_cast<unsigned>(n_par), static_cast<unsigned>((n_par + 2047) / 2048));
             hipLaunchKernelGGL(rows_compact_kernel, grid, dim3(256), 0, p->stream, psi, static_cast<long long>(s.ld_prev), none,
@@ -2888,13 +2908,12 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
             // 3S + 4S fused: new x dragged and its transpose in one pass over the parents' rows (rows_avg_t_kernel)
             const size_t lds = 64 * (kFT + 1) * sizeof(float);
             HIP_TRY(set_max_lds(reinterpret_cast<const void *>(rows_avg_t_kernel), lds));
-            for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) {
-                const int c_lo = s.live_ranges[h], len = s.live_ranges[h + 1] - c_lo;
+            if (d.n_tiles > 0) {
                 const int gf = p->tun.stay_col_fastest ? 0 : 1;
-                const unsigned nct = static_cast<unsigned>((len + kFT - 1) / kFT);
+                const unsigned nct = static_cast<unsigned>(d.n_tiles);
                 dim3 gt(gf ? static_cast<unsigned>(n_gran) : nct, gf ? nct : static_cast<unsigned>(n_gran));
                 hipLaunchKernelGGL(rows_avg_t_kernel, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
-                                   d.blk_slot, c_lo, len, cert_out, thr, gf);
+                                   d.blk_slot, d.tiles, cert_out, thr, gf);
                 HIP_TRY(hipGetLastError());
             }
             return GENPHI_OK;

@@ -431,7 +431,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         for (int32_t c = 2; c + 1 < L; ++c) {
             const bool by_width = blk[c] && blk[c + 1];                  // both steps assemble blocks anyway
             const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min && c + 2 < L &&      // (the reader is never the proband step)
-                                cost_stay(c) < (blk[c] ? cost_blk(c) : cost_rows(c));
+                                (opt.stay_narrow_force || cost_stay(c) < (blk[c] ? cost_blk(c) : cost_rows(c)));
             want[c] = (by_width || narrow) && 100 * size_of[c] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
                       size_of[c] > static_cast<int64_t>(new_of[c].size()) && nn_ok(c) && nn_ok(c + 1);
         }
@@ -444,7 +444,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             for (int32_t cc = c; cc <= e; ++cc) gain += (blk[cc] ? cost_blk(cc) : cost_rows(cc)) - cost_stay(cc);
             bool all_wide = blk[e + 1] != 0;
             for (int32_t cc = c; cc <= e; ++cc) all_wide = all_wide && blk[cc];
-            if (all_wide || gain > 0.0) run_end[c] = e;
+            if (all_wide || gain > 0.0 || opt.stay_narrow_force) run_end[c] = e;
             c = e + 1;
         }
     }
@@ -457,6 +457,10 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         // (every block of such a plan, the cuts above the region too: the cut a run starts from is made of them)
         for (int32_t c = 0; c + 1 < L && any_run; ++c) {
             if (new_of[c].size() < 2) continue;
+            // (inside a class: families together, by the father's rank, rank order inside a family -- the workgroup of
+            // rows_avg_t_kernel that holds a granule of 64 new rows then reads a father's row once for his children)
+            if (opt.stay_family_order)
+                std::stable_sort(new_of[c].begin(), new_of[c].end(), [&](int32_t a, int32_t b) { return fa[a] < fa[b]; });
             for (int32_t x : new_of[c]) key[x] = L - 1 - tfirst[x];      // the last cut x is in: early leavers first (the slots are
                                                                          // a circular queue: what entered first, or sits lowest, dies first)
             counting_sort(new_of[c], tmp, key, L, cnt);

@@ -113,7 +113,9 @@ struct PlanOptions {
     int32_t stay_slack_pct = 6;       // free slots a run starts with beyond its widest (cut + new members), in % (granules that are only partly dead)
     bool stay_narrow = true;          // cuts whose rows fit in LDS (FULL / SPLIT widths) may stay in place too: their steps are switched to block
                                       // assembly when the cost model says the dragged x dragged copy that is saved outweighs the extra passes
+    bool stay_narrow_force = false;   // A/B hook: ... whatever the cost model says (every step that passes the ratio test)
     int64_t stay_narrow_min = 2048;   // ... from this width of the source cut on (narrower levels are bound by their launches, not their bytes)
+    bool stay_family_order = true;    // new members of a cut of an in-place plan: siblings (same father) adjacent inside a leaving class
     int32_t stay_headroom = 0;        // extra blocks of free slots a run starts with (each the size of its largest block of new members):
                                       // more of them = longer runs before the slot space is full (memory: P grows)
 };
