@@ -90,13 +90,16 @@ def load_workload(name):
 
 
 def cpu_baseline(ped, pro, sizes, budget_s=20.0):
-    """The oracle (a C/OpenMP port of the reference algorithm, kind "port") timed on this
-    host's cores on a bounded sample: the first level steps of the same pedigree, until about
-    budget_s seconds of work; extrapolated to the whole sweep by (i <= j) kernel evaluations."""
+    """The oracle (a C/OpenMP port of the reference algorithm, kind "port") timed on this host's cores on a bounded
+    sample of the same workload: (i) the first level steps of the same pedigree, until about budget_s / 2 seconds of work,
+    (ii) rows of the LAST level step (the proband matrix: a third of the evaluations of cfg4, random access into the widest
+    source matrix) on the real index structure of that step.  Extrapolated to the whole sweep by (i <= j) kernel evaluations,
+    the upper steps at the rate of (i), the last one at the rate of (ii)."""
     from oracle import oracle as O
     oped = O.Pedigree(ped.ind, ped.father, ped.mother, sort=False)
-    evals_total = sum(n * (n + 1) // 2 for n in sizes[1:])
     n_pro = sizes[-1]
+    evals_upper = sum(n * (n + 1) // 2 for n in sizes[1:-1])
+    evals_last = n_pro * (n_pro + 1) // 2
     # choose how many level steps to run: probe one step, then size the sample
     t0 = time.perf_counter()
     _, done1 = oped.phi(pro, stop_after_levels=1) if len(sizes) > 2 else (None, 0)
@@ -121,12 +124,22 @@ def cpu_baseline(ped, pro, sizes, budget_s=20.0):
         t0 = time.perf_counter()
         _, done = oped.phi(pro, stop_after_levels=k)
         t = time.perf_counter() - t0
-    rate = done / t
-    t_est = evals_total / rate
+    rate_upper = done / t
+    # (ii) rows of the last level step, spread over the proband order, about a tenth of the budget
+    n_rows = int(max(1, min(n_pro, 256)))
+    rows = np.unique(np.linspace(0, n_pro - 1, n_rows).astype(np.int64))
+    t_last, done_last = oped.time_level_rows(pro, len(sizes) - 2, rows)
+    while t_last < budget_s / 20 and len(rows) < n_pro:
+        rows = np.unique(np.linspace(0, n_pro - 1, min(n_pro, 4 * len(rows))).astype(np.int64))
+        t_last, done_last = oped.time_level_rows(pro, len(sizes) - 2, rows)
+    rate_last = done_last / t_last
+    t_est = evals_upper / rate_upper + evals_last / rate_last
     return {"value": n_pro * n_pro / t_est, "unit": "proband-pairs/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"first {k} of {len(sizes) - 1} level steps of the same pedigree ({done:.3g} of {evals_total:.3g} "
-                      f"pair-kernel evaluations, {t:.1f} s, C/OpenMP oracle = port of src/compute.jl:105-158,233-304), "
-                      f"extrapolated by evaluation count"}
+            "sample": f"first {k} of {len(sizes) - 2} upper level steps of the same pedigree ({done:.3g} of {evals_upper:.3g} pair-kernel "
+                      f"evaluations, {t:.1f} s) + {len(rows)} rows of the last level step ({done_last:.3g} evaluations on the step's real "
+                      f"indices and a source matrix of the real size, {t_last:.2f} s; the step has {evals_last:.3g}); "
+                      f"C/OpenMP oracle = port of src/compute.jl:105-158,233-304; extrapolated by evaluation count, each part at its own rate",
+            "rates_evals_per_s": {"upper_levels": rate_upper, "last_level": rate_last}}
 
 
 def shard_rows(n, rank, world):
@@ -183,12 +196,13 @@ def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes,
             dist.barrier()
         torch.cuda.synchronize()
 
+    selftest = gdist.comm_selftest(dist, dev) if dist is not None else None
     for _ in range(max(args.warmup, 1)):
-        sent = gdist.panel_sweep(pl, dist, dev)
+        sent = gdist.panel_sweep(pl, dist, dev, ordered=not args.panel_host_sync)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sent = gdist.panel_sweep(pl, dist, dev)
+        sent = gdist.panel_sweep(pl, dist, dev, ordered=not args.panel_host_sync)
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
@@ -222,9 +236,10 @@ def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes,
                        "parallelism": f"column panels x{world}: every level storage-sharded, one all-to-all of parent columns per level step"
                                       + (" (all ranks share one GPU: rehearsal)" if args.single_device and world > 1 else ""),
                        "why_exchange": "forced" if fits else "two level matrices do not fit one GPU",
-                       "exchange_bytes_sent_per_rank_max": sent_max,
+                       "exchange_bytes_sent_per_rank_max": sent_max, "comm_selftest": selftest,
                        "panel_device_bytes": pl.device_bytes, "max_cut": max(cut_sizes),
                        "panel_step_modes": pl.step_modes() if hasattr(pl, "step_modes") else None,
+                       "ordering": "host synchronisation per step" if args.panel_host_sync else "stream events (no host synchronisation inside a sweep)",
                        "timed": "host wall clock around whole sweeps (pack, exchange through "
                                 + ("RCCL" if args.backend == "nccl" and world > 1 else "host memory (gloo)" if world > 1 else "nothing: one rank")
                                 + ", unpack, level kernels), max over ranks"},
@@ -306,6 +321,12 @@ def main():
                     help="N > 1: storage-sharded levels (column panels) with an all-to-all before every level step, "
                          "instead of replicated levels; taken automatically when the level matrices do not fit one GPU "
                          "(also GENPHI_FORCE_EXCHANGE=1)")
+    ap.add_argument("--pg", action="store_true",
+                    help="initialise the torch.distributed process group at N = 1 too (with --exchange: the RCCL communicator is created "
+                         "and a self-test all_to_all_single / all_reduce runs on it before the sweeps)")
+    ap.add_argument("--panel-host-sync", action="store_true",
+                    help="--exchange: order pack / collective / level kernels by host synchronisations per step (the round-3 form; A/B) "
+                         "instead of stream events")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing: plan + shard + barrier + max-reduce, no compute")
     args = ap.parse_args()
@@ -325,9 +346,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.pg and "RANK" not in os.environ:                     # not under the launcher: a one-rank group of its own
+            os.environ.setdefault("MASTER_PORT", "29571")
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:

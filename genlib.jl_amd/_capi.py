@@ -48,7 +48,8 @@ EXPORTED_SYMBOLS = [
     "genphi_last_error",
     "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
     "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_step_ms", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
-    "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_result_to_host",
+    "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_pack_on", "genphi_panel_compute_on", "genphi_panel_sync",
+    "genphi_panel_result_to_host",
     "genphi_panel_destroy",
 ]
 
@@ -84,9 +85,9 @@ def lib():
         L.genphi_plan_step_slots.argtypes = [C.c_void_p, C.c_int32, _I64P]
         L.genphi_plan_step_slots.restype = C.c_int
         _I32P = C.POINTER(C.c_int32)
-        if hasattr(L, "genphi_plan_step_walk"):            # (absent from older builds used in same-box A/B runs)
-            L.genphi_plan_step_walk.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P, _I32P, _I32P, _I32P]
-            L.genphi_plan_step_walk.restype = C.c_int
+        # (every symbol is bound unconditionally: this binding needs the build it was written for -- include/genphi.h)
+        L.genphi_plan_step_walk.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P, _I32P, _I32P, _I32P]
+        L.genphi_plan_step_walk.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -152,6 +153,12 @@ def lib():
         L.genphi_panel_pack.restype = C.c_int
         L.genphi_panel_compute.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.genphi_panel_compute.restype = C.c_int
+        L.genphi_panel_pack_on.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.genphi_panel_pack_on.restype = C.c_int
+        L.genphi_panel_compute_on.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.genphi_panel_compute_on.restype = C.c_int
+        L.genphi_panel_sync.argtypes = [C.c_void_p]
+        L.genphi_panel_sync.restype = C.c_int
         L.genphi_panel_result_to_host.argtypes = [C.c_void_p, _F32P]
         L.genphi_panel_result_to_host.restype = C.c_int
         L.genphi_panel_destroy.argtypes = [C.c_void_p]
@@ -443,7 +450,9 @@ class KinshipMatrix:
         if rc:
             _raise(rc)
         wm, wb = np.zeros(nw.value, np.float32), np.zeros(nw.value, np.float64)
-        lib().genphi_sparse_stats(self._h, None, None, None, None, wm.ctypes.data_as(_F32P), wb.ctypes.data_as(C.POINTER(C.c_double)), nw.value)
+        rc = lib().genphi_sparse_stats(self._h, None, None, None, None, wm.ctypes.data_as(_F32P), wb.ctypes.data_as(C.POINTER(C.c_double)), nw.value)
+        if rc:
+            _raise(rc)
         return {"n_waves": nw.value, "sweep_ms": ms.value, "algorithmic_bytes": ab.value, "max_active": ma.value, "wave_ms": wm, "wave_bytes": wb}
 
     def get(self, id1, id2):
@@ -543,6 +552,23 @@ class PanelPlan:
 
     def compute(self, step, d_recv_ptr):
         rc = lib().genphi_panel_compute(self._h, int(step), C.c_void_p(d_recv_ptr))
+        if rc:
+            _raise(rc)
+
+    def pack_on(self, step, d_send_ptr, stream):
+        """pack, ordered by streams: `stream` (a raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) waits for the packed columns."""
+        rc = lib().genphi_panel_pack_on(self._h, int(step), C.c_void_p(d_send_ptr), C.c_void_p(stream))
+        if rc:
+            _raise(rc)
+
+    def compute_on(self, step, d_recv_ptr, stream):
+        """compute, ordered by streams: the panel's stream waits for what `stream` holds (the collective), nothing blocks the host."""
+        rc = lib().genphi_panel_compute_on(self._h, int(step), C.c_void_p(d_recv_ptr), C.c_void_p(stream))
+        if rc:
+            _raise(rc)
+
+    def sync(self):
+        rc = lib().genphi_panel_sync(self._h)
         if rc:
             _raise(rc)
 

@@ -2798,6 +2798,21 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
 // ---- column panels (panel_phi.hip): a level step of a rank's panel through the same row kernels -------------
 const void *genphi::panel_tuning_create() { return new (std::nothrow) Tuning(tuning_from_env()); }
 void genphi::panel_tuning_destroy(const void *t) { delete static_cast<const Tuning *>(t); }
+int genphi::panel_tuning_lds_cap(const void *t, int dflt)
+{
+    const Tuning *u = static_cast<const Tuning *>(t);
+    return (u && u->lds_cap_floats >= 16) ? u->lds_cap_floats : dflt;
+}
+int genphi::panel_tuning_full_max(const void *t, int dflt)
+{
+    const Tuning *u = static_cast<const Tuning *>(t);
+    return (u && u->full_max_floats >= 0) ? u->full_max_floats : dflt;
+}
+unsigned genphi::panel_tuning_cert_thresh(const void *t)
+{
+    static const Tuning dflt;
+    return cert_threshold(t ? *static_cast<const Tuning *>(t) : dflt);
+}
 
 int genphi::launch_panel_level(const PanelLaunch &L)
 {

@@ -43,6 +43,9 @@ struct PanelLaunch {
 
 const void *panel_tuning_create();               // environment hooks, read once per panel handle
 void panel_tuning_destroy(const void *t);
+int panel_tuning_lds_cap(const void *t, int dflt);        // GENPHI_LDS_CAP_FLOATS (>= 16) or dflt
+int panel_tuning_full_max(const void *t, int dflt);       // GENPHI_FULL_MAX_FLOATS (>= 0) or dflt
+unsigned panel_tuning_cert_thresh(const void *t);         // certificate threshold word (GENPHI_CERT_MIN_EXP raises it)
 int launch_panel_level(const PanelLaunch &L);    // GENPHI_OK or an error code (message in genphi_last_error)
 
 }  // namespace genphi

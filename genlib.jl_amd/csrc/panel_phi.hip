@@ -197,7 +197,9 @@ struct genphi_panel {
     int glist_cap = 0, n_cus = 256;
     const void *tuning = nullptr;              // environment hooks (panel_tuning_create)
     bool naive = false;                        // GENPHI_PANEL_NAIVE: per-entry kernel on every step (A/B, tests)
-    hipEvent_t ev[2] = {nullptr, nullptr};     // around the kernels of the last genphi_panel_compute
+    std::vector<hipEvent_t> ev;                // two per level step: around the step's kernels (unpack + level) of the last sweep
+    hipEvent_t ev_x[2] = {nullptr, nullptr};   // ordering with the caller's stream: [0] packed columns complete, [1] received columns complete
+    std::vector<char> ev_pending;              // step_ms[k] not read back from its events yet
     std::vector<float> step_ms;                // device time of every step's kernels (unpack + level) in the last sweep
     int cur = 0;                               // panel[cur] holds the level of the last step computed
 };
@@ -210,7 +212,9 @@ static void panel_free_device(genphi_panel *p)
     auto rel = [](auto *&q) { if (q) (void)hipFree(q); q = nullptr; };
     rel(p->panel[0]); rel(p->panel[1]); rel(p->result);
     rel(p->d_cert[0]); rel(p->d_cert[1]); rel(p->d_counters); rel(p->d_glist);
-    for (hipEvent_t &e : p->ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t &e : p->ev) if (e) (void)hipEventDestroy(e);
+    p->ev.clear();
+    for (hipEvent_t &e : p->ev_x) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (DevPanelStep &d : p->d_step) { rel(d.pk_col); rel(d.ord_col); rel(d.diag_col); rel(d.work); rel(d.desc); rel(d.seg); rel(d.run); rel(d.pdesc); }
     p->d_step.clear();
     p->panel_floats[0] = p->panel_floats[1] = 0;
@@ -338,9 +342,9 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
         }
         // ---- the same step for the row kernels: a source "row" is a row of the extended panel (zcol + 1 floats) ----
         ps.src_width = zcol + 1;
-        int lds_cap = genphi::kPanelSplitMaxFloats, full_max = genphi::kPanelFullMaxFloats;
-        if (const char *e = std::getenv("GENPHI_LDS_CAP_FLOATS")) { const int v = std::atoi(e); if (v >= 16) lds_cap = v; }        // test hooks, as for plans
-        if (const char *e = std::getenv("GENPHI_FULL_MAX_FLOATS")) { const int v = std::atoi(e); if (v >= 0) full_max = v; }
+        // (test hooks, as for plans: read once per handle, in panel_tuning_create)
+        const int lds_cap = genphi::panel_tuning_lds_cap(p->tuning, genphi::kPanelSplitMaxFloats);
+        const int full_max = genphi::panel_tuning_full_max(p->tuning, genphi::kPanelFullMaxFloats);
         const int row4 = (ps.src_width + 3) / 4 * 4;
         ps.mode = p->naive ? 2 : (2 * row4 <= lds_cap && row4 <= full_max ? 0 : (row4 <= lds_cap && zcol < 65536 ? 1 : 2));
         if (ps.mode != 2) {
@@ -386,9 +390,16 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
 int64_t genphi_panel_n_steps(const genphi_panel *p) { return p ? std::max(p->plan.n_levels - 1, 0) : -1; }
 int64_t genphi_panel_n_probands(const genphi_panel *p) { return p ? p->plan.n_pro : -1; }
 /* device time (ms, HIP events) of the kernels of level step `step` in the last sweep: unpack of the received columns + the level kernel */
-double genphi_panel_step_ms(const genphi_panel *p, int32_t step)
+double genphi_panel_step_ms(const genphi_panel *cp, int32_t step)
 {
-    return (!p || step < 0 || step >= static_cast<int32_t>(p->step_ms.size())) ? -1.0 : static_cast<double>(p->step_ms[step]);
+    genphi_panel *p = const_cast<genphi_panel *>(cp);
+    if (!p || step < 0 || step >= static_cast<int32_t>(p->step_ms.size())) return -1.0;
+    if (p->on_device && p->ev_pending[step]) {               // a stream-ordered sweep: the events are read when somebody asks
+        (void)hipSetDevice(p->device);
+        if (hipEventSynchronize(p->ev[2 * step + 1]) == hipSuccess && hipEventElapsedTime(&p->step_ms[step], p->ev[2 * step], p->ev[2 * step + 1]) == hipSuccess)
+            p->ev_pending[step] = 0;
+    }
+    return static_cast<double>(p->step_ms[step]);
 }
 int genphi_panel_step_mode(const genphi_panel *p, int32_t step)
 {
@@ -491,8 +502,11 @@ static int panel_upload_impl(genphi_panel *p, int device)
         p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
     }
     p->glist_cap = static_cast<int>((pl.max_cut + 64) / 64 * 64);
+    p->ev.assign(2 * S, nullptr);
     for (hipEvent_t &e : p->ev) PN_TRY(hipEventCreate(&e));
+    for (hipEvent_t &e : p->ev_x) PN_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->step_ms.assign(S, 0.f);
+    p->ev_pending.assign(S, 0);
     for (int b = 0; b < 2; ++b) PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_cert[b]), (static_cast<size_t>(pl.max_cut) + 1) * sizeof(int)));
     PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_counters), 20 * sizeof(int)));
     PN_TRY(pmalloc(reinterpret_cast<void **>(&p->d_glist), 2 * static_cast<size_t>(p->glist_cap) * sizeof(int)));
@@ -555,25 +569,43 @@ int genphi_panel_begin(genphi_panel *p, int32_t device)
     return GENPHI_OK;
 }
 
-int genphi_panel_pack(genphi_panel *p, int32_t step, float *d_send)
+// Stream ordering with the host driver's collective (which runs on the DRIVER's stream, e.g. torch's current one):
+//   genphi_panel_pack_on(.., caller_stream)     the pack kernel is enqueued on the panel's stream and caller_stream is made to wait
+//                                               for it (an event): the collective enqueued next on caller_stream reads complete columns
+//   genphi_panel_compute_on(.., caller_stream)  the panel's stream waits for what caller_stream holds so far (the collective), then
+//                                               unpack + level kernels are enqueued; nothing blocks the host
+// caller_stream == nullptr: the blocking forms (genphi_panel_pack / _compute): a stream synchronisation at the end of each call.
+static int panel_pack_impl(genphi_panel *p, int32_t step, float *d_send, bool ordered, hipStream_t caller)
 {
     if (!p || step < 0 || step >= static_cast<int32_t>(p->steps.size())) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_pack: bad argument");
     if (!p->on_device) return genphi_set_error(GENPHI_ERR_DEVICE, "genphi_panel_begin first");
     PN_TRY(hipSetDevice(p->device));
     const PanelStep &ps = p->steps[step];
     const int n_send = static_cast<int>(ps.send_cols.size());
-    if (n_send == 0) return GENPHI_OK;
-    if (!d_send) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_pack: d_send is NULL");
-    const int n_rows = static_cast<int>(p->plan.steps[step].n_prev);
-    const long long ld = pitch(static_cast<long long>(p->member[step].size()) + ps.n_ext);
-    dim3 grid(static_cast<unsigned>(n_send), static_cast<unsigned>(std::min((n_rows + 255) / 256, 64)));
-    hipLaunchKernelGGL(panel_pack_kernel, grid, dim3(256), 0, p->stream, p->panel[step & 1], ld, n_rows, p->d_send_cols[step], d_send);
-    PN_TRY(hipGetLastError());
-    PN_TRY(hipStreamSynchronize(p->stream));               // the host driver's collective runs on another stream
+    if (n_send > 0) {
+        if (!d_send) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_pack: d_send is NULL");
+        const int n_rows = static_cast<int>(p->plan.steps[step].n_prev);
+        const long long ld = pitch(static_cast<long long>(p->member[step].size()) + ps.n_ext);
+        dim3 grid(static_cast<unsigned>(n_send), static_cast<unsigned>(std::min((n_rows + 255) / 256, 64)));
+        hipLaunchKernelGGL(panel_pack_kernel, grid, dim3(256), 0, p->stream, p->panel[step & 1], ld, n_rows, p->d_send_cols[step], d_send);
+        PN_TRY(hipGetLastError());
+    }
+    if (ordered) {
+        // (also with nothing to send: the driver's next collective overwrites the receive buffer, which the previous step's unpack reads)
+        PN_TRY(hipEventRecord(p->ev_x[0], p->stream));
+        PN_TRY(hipStreamWaitEvent(caller, p->ev_x[0], 0));
+    } else if (n_send > 0) {
+        PN_TRY(hipStreamSynchronize(p->stream));               // the host driver's collective runs on another stream
+    }
     return GENPHI_OK;
 }
+int genphi_panel_pack(genphi_panel *p, int32_t step, float *d_send) { return panel_pack_impl(p, step, d_send, false, nullptr); }
+int genphi_panel_pack_on(genphi_panel *p, int32_t step, float *d_send, void *caller_stream)
+{
+    return panel_pack_impl(p, step, d_send, true, static_cast<hipStream_t>(caller_stream));
+}
 
-int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
+static int panel_compute_impl(genphi_panel *p, int32_t step, const float *d_recv, bool ordered, hipStream_t caller)
 {
     if (!p || step < 0 || step >= static_cast<int32_t>(p->steps.size())) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_compute: bad argument");
     if (!p->on_device) return genphi_set_error(GENPHI_ERR_DEVICE, "genphi_panel_begin first");
@@ -585,12 +617,16 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
     const int n_own = static_cast<int>(p->member[step].size());
     const long long ldp = pitch(static_cast<long long>(n_own) + ps.n_ext);
     float *psi = p->panel[step & 1];
-    PN_TRY(hipEventRecord(p->ev[0], p->stream));
+    if (ordered) {                                             // the received columns are complete on the caller's stream
+        PN_TRY(hipEventRecord(p->ev_x[1], caller));
+        PN_TRY(hipStreamWaitEvent(p->stream, p->ev_x[1], 0));
+    }
+    PN_TRY(hipEventRecord(p->ev[2 * step], p->stream));
     if (ps.n_ext > 0) {
         if (!d_recv) return genphi_set_error(GENPHI_ERR_ARG, "genphi_panel_compute: d_recv is NULL");
         dim3 grid(static_cast<unsigned>((ps.n_ext + 63) / 64), static_cast<unsigned>((n_prev + 63) / 64));
         hipLaunchKernelGGL(panel_unpack_kernel, grid, dim3(256), 0, p->stream, psi, ldp, n_prev, n_own, ps.n_ext, d_recv,
-                           p->d_cert[step & 1], (static_cast<unsigned>(127 - 27) << 23) - 1u);
+                           p->d_cert[step & 1], genphi::panel_tuning_cert_thresh(p->tuning));
         PN_TRY(hipGetLastError());
     }
     const bool last = step + 1 == static_cast<int32_t>(p->steps.size());
@@ -622,10 +658,28 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv)
         PN_TRY(hipGetLastError());
         PN_TRY(hipMemsetAsync(cert_out, 0xff, static_cast<size_t>(n) * sizeof(int), p->stream));
     }
-    PN_TRY(hipEventRecord(p->ev[1], p->stream));
-    PN_TRY(hipStreamSynchronize(p->stream));
-    PN_TRY(hipEventElapsedTime(&p->step_ms[step], p->ev[0], p->ev[1]));
+    PN_TRY(hipEventRecord(p->ev[2 * step + 1], p->stream));
+    p->ev_pending[step] = 1;
     p->cur = (step + 1) & 1;
+    if (!ordered) {
+        PN_TRY(hipStreamSynchronize(p->stream));
+        PN_TRY(hipEventElapsedTime(&p->step_ms[step], p->ev[2 * step], p->ev[2 * step + 1]));
+        p->ev_pending[step] = 0;
+    }
+    return GENPHI_OK;
+}
+int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv) { return panel_compute_impl(p, step, d_recv, false, nullptr); }
+int genphi_panel_compute_on(genphi_panel *p, int32_t step, const float *d_recv, void *caller_stream)
+{
+    return panel_compute_impl(p, step, d_recv, true, static_cast<hipStream_t>(caller_stream));
+}
+/* Waits for everything the panel's stream holds (the end of a stream-ordered sweep). */
+int genphi_panel_sync(genphi_panel *p)
+{
+    if (!p) return genphi_set_error(GENPHI_ERR_ARG, "panel handle is NULL");
+    if (!p->on_device) return GENPHI_OK;
+    PN_TRY(hipSetDevice(p->device));
+    PN_TRY(hipStreamSynchronize(p->stream));
     return GENPHI_OK;
 }
 

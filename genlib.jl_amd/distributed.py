@@ -48,39 +48,80 @@ def _exchange(dist, send, recv, send_cols, recv_cols, col_floats):
     recv[:n_recv].copy_(hr)
 
 
-def panel_sweep(pl, dist, dev):
+def comm_selftest(dist, dev):
+    """Communicator check before the first sweep: one all_to_all_single of rank-stamped columns (the collective of
+    _exchange, uneven splits included) and one MAX all-reduce on `dev` tensors, verified on every rank.  With the
+    "nccl" backend this is RCCL -- also at world size 1, where the exchange lists themselves are empty."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_dev = dist.get_backend() == "nccl"
+    d = dev if on_dev else torch.device("cpu")
+    # rank r sends (d + 1) * 3 floats to rank d, each stamped 1000 r + d
+    in_splits = [(q + 1) * 3 for q in range(world)]
+    out_splits = [(rank + 1) * 3] * world
+    send = torch.cat([torch.full((n,), 1000.0 * rank + q, dtype=torch.float32) for q, n in enumerate(in_splits)]).to(d)
+    recv = torch.full((sum(out_splits),), -1.0, dtype=torch.float32, device=d)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits)
+    want = torch.cat([torch.full((out_splits[q],), 1000.0 * q + rank, dtype=torch.float32) for q in range(world)])
+    ok = bool(torch.equal(recv.cpu(), want))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=d)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world)
+    return {"backend": dist.get_backend(), "world": world, "device_tensors": on_dev, "all_to_all_single_ok": ok}
+
+
+def panel_sweep(pl, dist, dev, ordered=True):
     """One gen.phi sweep on an existing PanelPlan: begin, then pack / all-to-all / compute per level
     step.  The result stays resident (this rank's column panel of Phi).  Returns bytes sent.
 
     The send / receive buffers are allocated once per plan at the largest step's size.  Ordering between
-    the library's stream and torch's: genphi_panel_pack returns when the packed columns are complete
-    (the collective may start), and the collective is complete on torch's current stream before
-    genphi_panel_compute is enqueued (one stream synchronisation per step, no device-wide ones)."""
+    the library's stream and torch's is by EVENTS, not by host synchronisation (genphi_panel_pack_on /
+    _compute_on): torch's current stream waits for the packed columns before the collective starts, the
+    library's stream waits for the collective before it unpacks, and the host runs ahead enqueueing the
+    next step; one synchronisation at the end of the sweep.  ordered=False is the round-3 form (a stream
+    synchronisation after pack, after the collective and after the level kernels of every step: A/B)."""
+    import time
     import torch
     pl.begin(device=dev.index)
-    counts = [pl.exchange_counts(step) for step in range(pl.n_steps)]
+    counts = getattr(pl, "_xcounts", None)
+    if counts is None:
+        counts = pl._xcounts = [pl.exchange_counts(step) for step in range(pl.n_steps)]
     bufs = getattr(pl, "_xbufs", None)
     if bufs is None:
         n_s = max([int(s.sum()) * cf for s, _, cf in counts] + [1])
         n_r = max([int(r.sum()) * cf for _, r, cf in counts] + [1])
         bufs = pl._xbufs = (torch.empty(n_s, dtype=torch.float32, device=dev), torch.empty(n_r, dtype=torch.float32, device=dev))
-    import time
     send, recv = bufs
+    sp, rp = send.data_ptr(), recv.data_ptr()
     sent = 0
+    t_begin = time.perf_counter()
+    if ordered:
+        stream = torch.cuda.current_stream(dev).cuda_stream          # raw hipStream_t the collective is enqueued on
+        for step, (s_cols, r_cols, cf) in enumerate(counts):
+            pl.pack_on(step, sp, stream)
+            _exchange(dist, send, recv, s_cols, r_cols, cf)
+            pl.compute_on(step, rp, stream)
+            sent += int(s_cols.sum()) * cf * 4
+        t_enq = time.perf_counter()
+        pl.sync()
+        t_end = time.perf_counter()
+        pl.last_sweep = {"ordered_by": "events", "host_enqueue_ms": (t_enq - t_begin) * 1e3, "sweep_wall_ms": (t_end - t_begin) * 1e3}
+        return sent
     t_pack = t_xchg = t_comp = 0.0
     for step, (s_cols, r_cols, cf) in enumerate(counts):
         t0 = time.perf_counter()
-        pl.pack(step, send.data_ptr())
+        pl.pack(step, sp)
         t1 = time.perf_counter()
         _exchange(dist, send, recv, s_cols, r_cols, cf)
         torch.cuda.current_stream(dev).synchronize()
         t2 = time.perf_counter()
-        pl.compute(step, recv.data_ptr())
+        pl.compute(step, rp)
         t3 = time.perf_counter()
         t_pack += t1 - t0; t_xchg += t2 - t1; t_comp += t3 - t2
         sent += int(s_cols.sum()) * cf * 4
     # host wall time of the three phases of the last sweep (each ends with a stream synchronisation)
-    pl.last_sweep = {"pack_ms": t_pack * 1e3, "exchange_ms": t_xchg * 1e3, "compute_ms": t_comp * 1e3}
+    pl.last_sweep = {"ordered_by": "host synchronisation", "pack_ms": t_pack * 1e3, "exchange_ms": t_xchg * 1e3, "compute_ms": t_comp * 1e3,
+                     "sweep_wall_ms": (time.perf_counter() - t_begin) * 1e3}
     return sent
 
 

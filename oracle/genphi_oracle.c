@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <stdio.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -383,6 +384,87 @@ int oracle_phi_compute(oracle_ped *p, const oracle_levels *lv, float *out,
     }
     free(Psi);
     return ORACLE_OK;
+}
+
+/* Row samples of the LAST level step (test infrastructure for sizes at which the whole matrix costs minutes):
+ * every upper level step in full, exactly as oracle_phi_compute, then only the given rows of the proband matrix
+ * (positions in probandIDs order).  Entry (r, j) is evaluated as the reference evaluates it -- the pair in index
+ * order, phi(probands[min(r, j)], probands[max(r, j)], Psi) (src/compute.jl:295-296: only i <= j, mirrored store).
+ * out: n_rows x n_L Float32, row-major. */
+int oracle_phi_compute_rows(oracle_ped *p, const oracle_levels *lv, int64_t n_rows, const int64_t *rows, float *out,
+                            int64_t *entries_done)
+{
+    const int32_t L = lv->n_levels;
+    memset(p->founder_index, 0, (size_t)p->n * sizeof(int32_t));   /* fresh _index_pedigree :269 */
+    int64_t n1 = lv->cut[0].n;
+    float *Psi = (float *)calloc((size_t)(n1 * n1 + 1), sizeof(float));  /* :271 */
+    if (!Psi) return ORACLE_ERR_ALLOC;
+    for (int64_t i = 0; i < n1; i++) Psi[i * n1 + i] = 0.5f;       /* :272-274 */
+    int64_t ld = n1, done = 0;
+    for (int32_t k = 0; k + 1 < L; k++) {                          /* :276 */
+        const ivec prev = lv->cut[k], next = lv->cut[k + 1];
+        for (int64_t t = 0; t < prev.n; t++) p->founder_index[prev.v[t]] = (int32_t)(t + 1);  /* :287-289 */
+        const int64_t n = next.n;
+        if (k + 2 == L) {                                          /* the last step: the sampled rows only */
+            #pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t q = 0; q < n_rows; q++) {
+                const int64_t r = rows[q];
+                for (int64_t j = 0; j < n; j++) {
+                    const int64_t a = r < j ? r : j, b = r < j ? j : r;
+                    out[q * n + j] = (float)level_rec(p, next.v[a], next.v[b], Psi, ld);
+                }
+            }
+            done += n_rows * n;
+            break;
+        }
+        float *phi = (float *)malloc((size_t)(n * n + 1) * sizeof(float));                     /* :291 */
+        if (!phi) { free(Psi); return ORACLE_ERR_ALLOC; }
+        #pragma omp parallel for schedule(dynamic, 8) if (n >= 512)
+        for (int64_t i = 0; i < n; i++) {                          /* :293-299 */
+            for (int64_t j = i; j < n; j++) {
+                float v = (float)level_rec(p, next.v[i], next.v[j], Psi, ld);
+                phi[i * n + j] = v; phi[j * n + i] = v;            /* :296 */
+            }
+        }
+        done += n * (n + 1) / 2;
+        free(Psi); Psi = phi; ld = n;                              /* :301 */
+    }
+    if (L == 1) for (int64_t q = 0; q < n_rows; q++) memcpy(out + q * n1, Psi + rows[q] * n1, (size_t)n1 * sizeof(float));
+    if (entries_done) *entries_done = done;
+    free(Psi);
+    return ORACLE_OK;
+}
+
+/* Timing sample for bench.py's cpu_baseline (never a result): the pair kernel over n_rows rows x all columns of level
+ * step k (cut k -> cut k + 1) with the real index structure of that step, on a matrix Psi of the real size that holds
+ * arbitrary values -- the control flow and the memory accesses of src/compute.jl:105-158 depend on founder_index, father,
+ * mother and rank only, not on the values.  Returns the evaluations done and, in *seconds, the wall time of the evaluations alone (the matrix is filled before). */
+int64_t oracle_time_level_rows(oracle_ped *p, const oracle_levels *lv, int32_t k, int64_t n_rows, const int64_t *rows, double *seconds)
+{
+    if (k < 0 || k + 1 >= lv->n_levels) return 0;
+    memset(p->founder_index, 0, (size_t)p->n * sizeof(int32_t));
+    const ivec prev = lv->cut[k], next = lv->cut[k + 1];
+    for (int64_t t = 0; t < prev.n; t++) p->founder_index[prev.v[t]] = (int32_t)(t + 1);
+    const int64_t ld = prev.n, n = next.n;
+    float *Psi = (float *)malloc((size_t)(ld * ld + 1) * sizeof(float));
+    if (!Psi) return -1;
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < ld * ld; i++) Psi[i] = 0.25f;           /* (first touch spreads the pages over the threads) */
+    double sink = 0.;
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    #pragma omp parallel for schedule(dynamic, 1) reduction(+ : sink)
+    for (int64_t q = 0; q < n_rows; q++) {
+        const int64_t r = rows[q];
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t a = r < j ? r : j, b = r < j ? j : r;
+            sink += (float)level_rec(p, next.v[a], next.v[b], Psi, ld);
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (seconds) *seconds = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+    free(Psi);
+    return sink >= 0. ? n_rows * n : -2;
 }
 
 /* src/compute.jl:454-459 phiMean(::Matrix{Float32}) with plain left-to-right Float32 sums.

@@ -52,6 +52,9 @@ def lib():
         L.oracle_levels_cut_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _I64P]
         L.oracle_levels_cut_ids.restype = None
         L.oracle_phi_compute.argtypes = [C.c_void_p, C.c_void_p, _F32P, C.c_int32, _I64P]
+        L.oracle_phi_compute_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, _I64P, _F32P, _I64P]
+        L.oracle_time_level_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, _I64P, C.POINTER(C.c_double)]
+        L.oracle_time_level_rows.restype = C.c_int64
         L.oracle_phi_mean.argtypes = [_F32P, C.c_int64]
         L.oracle_phi_mean.restype = C.c_float
         L.oracle_num_threads.restype = C.c_int
@@ -183,6 +186,45 @@ class Pedigree:
             L.oracle_levels_free(lv)
         return out
 
+
+    def phi_rows(self, pro, rows):
+        """Rows `rows` (positions in `pro`) of gen.phi(ped, pro): every upper level step in full, the last one for the
+        sampled rows only (what a test can afford at sizes whose whole matrix costs minutes).  (len(rows), N) Float32."""
+        L = lib()
+        pro, rows = _i64(pro), _i64(rows)
+        lv = C.c_void_p()
+        if L.oracle_levels_create(self._h, len(pro), _p(pro), C.byref(lv)):
+            raise OracleError("unknown proband ID")
+        try:
+            nl = L.oracle_levels_count(lv)
+            n = L.oracle_levels_cut_size(lv, nl - 1)
+            if len(rows) and (rows.min() < 0 or rows.max() >= n):
+                raise IndexError("row out of range")
+            out = np.empty((len(rows), n), dtype=np.float32)
+            done = C.c_int64(0)
+            if L.oracle_phi_compute_rows(self._h, lv, len(rows), _p(rows), out.ctypes.data_as(_F32P), C.byref(done)):
+                raise MemoryError("oracle_phi_compute_rows")
+        finally:
+            L.oracle_levels_free(lv)
+        return out
+
+    def time_level_rows(self, pro, step, rows):
+        """Timing sample (bench.py cpu_baseline): seconds and pair-kernel evaluations of `rows` x all columns of level
+        step `step`, real index structure, a matrix of the real size with arbitrary values (see the C source)."""
+        L = lib()
+        pro, rows = _i64(pro), _i64(rows)
+        lv = C.c_void_p()
+        if L.oracle_levels_create(self._h, len(pro), _p(pro), C.byref(lv)):
+            raise OracleError("unknown proband ID")
+        try:
+            sec = C.c_double(0.0)
+            done = L.oracle_time_level_rows(self._h, lv, step, len(rows), _p(rows), C.byref(sec))
+            dt = sec.value
+        finally:
+            L.oracle_levels_free(lv)
+        if done < 0:
+            raise MemoryError("oracle_time_level_rows")
+        return dt, int(done)
 
     def branching(self, pro=None, ancestors=None):
         """gen.branching (src/extract.jl:65-186), restated as written there: build the

@@ -137,3 +137,19 @@ def test_bench_exchange_mode_two_ranks_one_gpu():
                     "--no-cpu-baseline", "--exchange"], 29537)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["why_exchange"] == "forced"
     assert d["config"]["exchange_bytes_sent_per_rank_max"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_at_one_rank():
+    """The collective of the exchange path on RCCL, as far as one GPU allows: bench.py --exchange under the launcher with ONE rank,
+    backend "nccl" -- the process group and its RCCL communicator are created, distributed.comm_selftest runs the very
+    all_to_all_single of _exchange (uneven splits) and a MAX all-reduce on device tensors, the sweeps run with the group alive,
+    and the timing reduction goes through an RCCL all-reduce.  (More than one rank per GPU is refused by RCCL: the multi-rank
+    rehearsals above use gloo.)"""
+    d = _launch(1, ["--workload", "cfg3", "--steps", "3", "--warmup", "1", "--backend", "nccl", "--no-cpu-baseline", "--exchange", "--pg"], 29538)
+    st = d["config"]["comm_selftest"]
+    assert st == {"backend": "nccl", "world": 1, "device_tensors": True, "all_to_all_single_ok": True}, st
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["exchange_bytes_sent_per_rank_max"] == 0
+    # no host synchronisation inside a sweep: the wall time of a sweep is the kernels' time plus little
+    per_rank = d["roofline"]["per_rank_kernels"]
+    assert d["ms_per_step"] <= 1.35 * per_rank["device_ms_per_sweep"] + 0.15, (d["ms_per_step"], per_rank)

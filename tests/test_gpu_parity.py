@@ -569,6 +569,48 @@ def test_full_size_cfg4_properties(gen):
     pl.close()
 
 
+def _resident_rows(pl, rows, chunk=32):
+    """Rows `rows` of the resident N x N result (after a full compute_device) without copying the matrix: point lookups."""
+    n = pl.n_probands
+    out = np.empty((len(rows), n), dtype=np.float32)
+    cols = np.arange(n, dtype=np.int64)
+    for a in range(0, len(rows), chunk):
+        rr = np.asarray(rows[a:a + chunk], dtype=np.int64)
+        got = pl.result_entries(np.repeat(rr, n), np.tile(cols, len(rr)))
+        out[a:a + len(rr)] = got.reshape(len(rr), n).astype(np.float32)          # (Float32 values read as Float64: exact)
+    return out
+
+
+def test_full_size_cfg4_oracle_row_sample(gen, oracle):
+    """The headline configuration at FULL size (1e6 individuals / 1e5 probands / 30 generations, the bench's default workload)
+    against the ORACLE, not against another HIP kernel: every upper level step of src/compute.jl:291-299 restated in full on the
+    host (8.3e9 pair evaluations), then ~158 rows of the 1e5 x 1e5 proband matrix -- the first and the last rows of the last
+    step's work queue, rows spread over the proband order, the two corner rows -- bit for bit against the same rows of the
+    matrix the default sweep left in HBM (the 4-chunk <512, 52, 16> instantiation of the certified-rows kernel writes them:
+    each row crosses all four column chunks).  Row sums of the whole result tie the sampled sweep to the checksums that
+    test_full_size_cfg4_properties compares across kernels."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(1_000_000, 100_000, 30)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    n = pl.n_probands
+    modes = pl.step_modes()
+    assert n == 100_000 and set(modes) == {1}
+    desc, seg, run = pl.step_walk(len(modes) - 1)
+    order = desc[:, 1].astype(np.int64)                              # output rows in work-queue order
+    assert len(order) == n and len(np.unique(order)) == n
+    rows = np.unique(np.concatenate([order[:48], order[-48:], np.linspace(0, n - 1, 59).astype(np.int64), [50_000, 50_001, 50_002]]))
+    want = oracle.Pedigree(ind, fa, mo).phi_rows(pro, rows)          # (~1.5 min on the box's cores)
+    pl.compute_device()
+    got = _resident_rows(pl, rows)
+    _assert_equal(got, want)
+    # the same rows as a row shard of their own (shard work lists, pruned upper levels)
+    k0 = int(np.searchsorted(rows, 50_000))
+    assert list(rows[k0:k0 + 3]) == [50_000, 50_001, 50_002]
+    _assert_equal(pl.compute(rows=(50_000, 50_003)), want[k0:k0 + 3])
+    pl.close()
+
+
 def test_full_size_cfg4o_properties(gen):
     """The overlapping-generations workload of the bench at full size (1e6 individuals / 1e5 probands, 0.5 % of the
     parents from g-2: cuts to 123.5k members, 23 WIDE levels, both routes for the dragged blocks, source
