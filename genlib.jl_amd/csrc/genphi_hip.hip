@@ -38,8 +38,11 @@
 //       the chunk's perm words and values in registers, coalesced 16-byte loads and stores.
 //   No MFMA anywhere: this is a gather-average, HBM-bound.
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -683,7 +686,9 @@ level_split_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 
 //   1 fma, 1 conversion per entry instead of 4 + 3 + 1 + 1 and the grouping selects; no rank words,
 //   no per-child masks (so groups of up to 8 children in every level), fewer registers.
 // Bit-identical to the grouping-exact kernel on certified rows (tests force both on the same input).
-template <int NTHREADS, int CPT, int STG, bool CERT>
+// CHAIN: the run lists may hold chain steps (type-1 segments: GENPHI_MAX_RUN > 1).  The default lists (one hub per run) never do,
+// and their instantiation carries none of that state -- the kernel is at the SGPR limit.
+template <int NTHREADS, int CPT, int STG, bool CERT, bool CHAIN>
 __global__ void __launch_bounds__(NTHREADS)
 level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const int4 *__restrict__ seg, const int4 *__restrict__ run,
                         const int *__restrict__ glist, const int2 *__restrict__ pdesc, int *queue)
@@ -774,7 +779,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
                 seg_step = true;
                 nsg = seg[g + 1];
                 n_we = seg[g + 2].x;
-                chain = nsg.w == 1;
+                chain = CHAIN && nsg.w == 1;
                 nextB = (nsg.x + nsg.z < n_we) ? desc[nsg.x + nsg.z].z : p.n_prev;
             } else {
                 nextB = p.n_prev;
@@ -844,7 +849,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             }
             if (CERT) { if (ck < p.cert_thresh) p.cert_out[ri] = 1; }     // plain store: the words only ever go 0 -> 1
         }
-        if (stage_is_a || chain) {
+        if (CHAIN ? (stage_is_a || chain) : stage_is_a) {
             // the expansion of the staged row: the hub of this segment (stage A), or -- the row is still in LDS -- of the
             // NEXT one (chain step: no hub row is staged for it).  ONE site writes pab: a second one inside the loop above
             // costs ~1.5 VGPRs per column (spills).
@@ -857,8 +862,9 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
                 pab[k] = (static_cast<double>(sR[pkk & 0xffff]) + static_cast<double>(sR[pkk >> 16])) * 0.25;
             }
             // the (new) hub's rows without B source lead its segment
-            wfin_b = stage_is_a ? wb : nsg.x;
-            wfin_e = wfin_b + (stage_is_a ? n0 : nsg.z);
+            const bool from_chain = CHAIN && !stage_is_a;
+            wfin_b = from_chain ? nsg.x : wb;
+            wfin_e = wfin_b + (from_chain ? nsg.z : n0);
         }
         // rows without a B source (dragged or one-parent rows of the hub): finish from pab alone
         for (int wf = wfin_b; wf < wfin_e; ++wf) {
@@ -894,7 +900,7 @@ level_split_fast_kernel(const LevelArgs p, const int4 *__restrict__ desc, const 
             w = w + 1;
         } else if (seg_step) {                          // next segment of the run: hub = the row just staged (type 1) or the same hub (type 2)
             g = g + 1;
-            if (chain) Ai = Bi;
+            if (CHAIN && chain) Ai = Bi;
             wb = nsg.x; we = n_we; n0 = nsg.z;
             w = wb + n0;
         }
@@ -1842,6 +1848,21 @@ colperm_kernel(const float *__restrict__ in, float *__restrict__ out, long long 
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+// GENPHI_TRACE=1: wall-clock marks of the phases of a compute call on stderr (where does a first call go?)
+struct PhaseTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    PhaseTrace() : on(std::getenv("GENPHI_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), last(t0) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[genphi trace] %-28s +%8.3f ms  (at %8.3f ms)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+                     std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 int genphi_set_error(int code, const std::string &msg) { return fail(code, msg); }   // for loader.cpp
 
 #define HIP_TRY(expr)                                                                           \
@@ -1896,6 +1917,8 @@ struct Tuning {
     bool no_graph = false;         // GENPHI_NO_GRAPH         A-B: never replay a captured hipGraph
     int d2h_threads = 0;           // GENPHI_D2H_THREADS      tuning: worker threads of genphi_result_to_host
     bool d2h_pageable = false;     // GENPHI_D2H_PAGEABLE     A-B: no pinned staging ring
+    int d2h_sym = -1;              // GENPHI_D2H_SYM          opt-in: 1 = a full result crosses the link as upper-triangle tiles + a host mirror pass (default: every entry is copied)
+    int d2h_tile_rows = 0, d2h_tile_cols = 0;   // GENPHI_D2H_TILE "RxC"  test + tuning: tile of the symmetric copy (default 256 x 8192)
     int fail_alloc_at = 0;         // GENPHI_TEST_FAIL_ALLOC  test: the k-th device allocation of an upload fails (error-path test)
 };
 
@@ -1939,6 +1962,11 @@ static Tuning tuning_from_env()
     t.no_graph = has("GENPHI_NO_GRAPH");
     t.d2h_threads = geti("GENPHI_D2H_THREADS", 0);
     t.d2h_pageable = has("GENPHI_D2H_PAGEABLE");
+    t.d2h_sym = geti("GENPHI_D2H_SYM", -1);
+    if (const char *e = std::getenv("GENPHI_D2H_TILE")) {
+        int r = 0, c = 0;
+        if (std::sscanf(e, "%dx%d", &r, &c) == 2 && r >= 1 && c >= 1) { t.d2h_tile_rows = r; t.d2h_tile_cols = c; }
+    }
     t.fail_alloc_at = geti("GENPHI_TEST_FAIL_ALLOC", 0);
     return t;
 }
@@ -2545,13 +2573,13 @@ static hipError_t launch_split(int cpt, int stg, int grid, size_t lds, hipStream
 // certified-rows kernel: 1024-thread workgroups (4 waves per SIMD, 128 VGPRs) or 512-thread ones
 // (2 waves per SIMD, 256 VGPRs: the per-thread overhead is paid half as often, so a workgroup
 // holds ~25 % more columns -- 4 column chunks instead of 5 for the 1e5-wide final level of cfg4)
-template <int NT, int C, int S, bool CERT>
+template <int NT, int C, int S, bool CERT, bool CHAIN>
 static hipError_t launch_fast_inst(int grid, size_t lds, hipStream_t stream, const LevelArgs &a, const int4 *desc,
                                    const int4 *grp, const int4 *run, int *queue)
 {
-    hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT>), lds);
+    hipError_t e = set_max_lds(reinterpret_cast<const void *>(level_split_fast_kernel<NT, C, S, CERT, CHAIN>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, run, a.glist, a.pdesc, queue);
+    hipLaunchKernelGGL((level_split_fast_kernel<NT, C, S, CERT, CHAIN>), dim3(grid), dim3(NT), lds, stream, a, desc, grp, run, a.glist, a.pdesc, queue);
     return hipGetLastError();
 }
 
@@ -2563,11 +2591,11 @@ static int fast_max_cpt(int nt, int stg)
     return stg <= 12 ? 52 : (stg <= 16 ? 56 : 48);
 }
 
-template <bool CERT>
+template <bool CERT, bool CHAIN>
 static hipError_t launch_fast(int nt, int cpt, int stg, int grid, size_t lds, hipStream_t stream, const LevelArgs &a,
                               const int4 *desc, const int4 *grp, const int4 *run, int *queue)
 {
-#define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT>(grid, lds, stream, a, desc, grp, run, queue)
+#define GENPHI_F(N, C, S) if (nt == N && cpt <= C && stg == S) return launch_fast_inst<N, C, S, CERT, CHAIN>(grid, lds, stream, a, desc, grp, run, queue)
 #ifdef GENPHI_MIN_INST
     GENPHI_F(1024, 16, 2); GENPHI_F(1024, 24, 8); GENPHI_F(512, 56, 16);
 #else
@@ -2727,8 +2755,15 @@ static int launch_rows(const LaunchRes &R, LevelArgs a, int mode, bool pos_ord, 
             f.n_chunks = f_chunks;
             f.n_groups = dg.n_runs;
             const int f_grid = static_cast<int>(std::min<long long>(R.n_cus, (f_items + 7) / 8 * 8));
-            HIP_TRY(f.cert_out ? launch_fast<true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue)
-                               : launch_fast<false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue));
+            // (the run lists hold chain steps only under GENPHI_MAX_RUN > 1: the default instantiation carries none of that state)
+            hipError_t fe;
+            if (R.tun->max_run > 1)
+                fe = f.cert_out ? launch_fast<true, true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue)
+                                : launch_fast<false, true>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue);
+            else
+                fe = f.cert_out ? launch_fast<true, false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue)
+                                : launch_fast<false, false>(f_nt, f_cpt, f_stg, f_grid, f_lds_stage + 32, R.stream, f, dg.desc, dg.seg, dg.run, queue);
+            HIP_TRY(fe);
             a.zero_row = 0;                                                   // the fast launch wrote the "none" row
             a.glist = glist_s; a.gcnt = gcnt_s;
         }
@@ -3146,8 +3181,10 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     const int L = pl.n_levels;
     if (L == 0 || r1 == r0) { p->res_ld = 0; return GENPHI_OK; }
 
+    PhaseTrace trace;
     int rc = upload_plan(p, device);
     if (rc) return rc;
+    trace.mark("upload_plan");
     p->res_f64 = opts && (opts->flags & GENPHI_FLAG_STORAGE_F64);
     if (p->res_f64) {
         p->res_ld = pl.ld[L - 1];
@@ -3157,6 +3194,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     p->stay_active = kernel != 1;             // the per-entry kernel sweep (kernel = 1) knows no slots: every level is written compactly
     rc = ensure_level_buffers(p);
     if (rc) return rc;
+    trace.mark("ensure_level_buffers");
     const int n_steps = L - 1;
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
@@ -3168,6 +3206,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     const int64_t N = pl.n_pro, ldN = pl.ld[L - 1], n_rows = r1 - r0;
     rc = ensure_floats(p, &p->result, &p->result_floats, static_cast<size_t>(n_rows * ldN));
     if (rc) return rc;
+    trace.mark("result buffer");
     p->res_ld = ldN;
     // last step WIDE: the whole level (every row, [dragged, new] storage order) goes to final_tmp,
     // then rows [r0, r1) are delivered in proband order by colperm_kernel
@@ -3297,6 +3336,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         }
     }
 
+    trace.mark("shard lists");
     // ---- the sweep: every launch of one gen.phi, in stream order ------------------------------
     const int prune_min_step = p->tun.shard_prune_min_step;                     // debugging aid
     const bool small_off = p->tun.no_small;                                      // test hook: per-level launches only
@@ -3442,7 +3482,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         }
     }
     if (timing && n_steps == 0) HIP_TRY(hipEventRecord(p->events[1], p->stream));
+    trace.mark("sweep enqueued");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    trace.mark("sweep done");
     if (timing) {
         const int ne = std::max(n_steps, 1);
         float ms = 0.f;
@@ -3489,6 +3531,38 @@ int genphi_result_to_host_f64(genphi_plan *p, double *out)
     return GENPHI_OK;
 }
 
+}  // extern "C"
+// tmp[q * nr + r] = src[r * w + q] for q < 16 and the first nr - nr % 8 rows r (genphi_result_to_host's mirror pass): 8 x 8
+// transposes in AVX2 registers.  Returns the rows done.  (Host code of one function: the library is not built with -mavx2.)
+__attribute__((target("avx2"))) static size_t mirror_gather16_avx2(const float *src, size_t w, size_t nr, float *tmp)
+{
+    size_t r = 0;
+    for (; r + 8 <= nr; r += 8) {
+        for (int h = 0; h < 2; ++h) {                       // columns [8 h, 8 h + 8)
+            __m256 v[8];
+            for (int k = 0; k < 8; ++k) v[k] = _mm256_loadu_ps(src + (r + k) * w + 8 * h);
+            const __m256 t0 = _mm256_unpacklo_ps(v[0], v[1]), t1 = _mm256_unpackhi_ps(v[0], v[1]);
+            const __m256 t2 = _mm256_unpacklo_ps(v[2], v[3]), t3 = _mm256_unpackhi_ps(v[2], v[3]);
+            const __m256 t4 = _mm256_unpacklo_ps(v[4], v[5]), t5 = _mm256_unpackhi_ps(v[4], v[5]);
+            const __m256 t6 = _mm256_unpacklo_ps(v[6], v[7]), t7 = _mm256_unpackhi_ps(v[6], v[7]);
+            const __m256 u0 = _mm256_shuffle_ps(t0, t2, 0x44), u1 = _mm256_shuffle_ps(t0, t2, 0xee);
+            const __m256 u2 = _mm256_shuffle_ps(t1, t3, 0x44), u3 = _mm256_shuffle_ps(t1, t3, 0xee);
+            const __m256 u4 = _mm256_shuffle_ps(t4, t6, 0x44), u5 = _mm256_shuffle_ps(t4, t6, 0xee);
+            const __m256 u6 = _mm256_shuffle_ps(t5, t7, 0x44), u7 = _mm256_shuffle_ps(t5, t7, 0xee);
+            _mm256_storeu_ps(tmp + (8 * h + 0) * nr + r, _mm256_permute2f128_ps(u0, u4, 0x20));
+            _mm256_storeu_ps(tmp + (8 * h + 1) * nr + r, _mm256_permute2f128_ps(u1, u5, 0x20));
+            _mm256_storeu_ps(tmp + (8 * h + 2) * nr + r, _mm256_permute2f128_ps(u2, u6, 0x20));
+            _mm256_storeu_ps(tmp + (8 * h + 3) * nr + r, _mm256_permute2f128_ps(u3, u7, 0x20));
+            _mm256_storeu_ps(tmp + (8 * h + 4) * nr + r, _mm256_permute2f128_ps(u0, u4, 0x31));
+            _mm256_storeu_ps(tmp + (8 * h + 5) * nr + r, _mm256_permute2f128_ps(u1, u5, 0x31));
+            _mm256_storeu_ps(tmp + (8 * h + 6) * nr + r, _mm256_permute2f128_ps(u2, u6, 0x31));
+            _mm256_storeu_ps(tmp + (8 * h + 7) * nr + r, _mm256_permute2f128_ps(u3, u7, 0x31));
+        }
+    }
+    return r;
+}
+extern "C" {
+
 int genphi_result_to_host(genphi_plan *p, float *out)
 {
     if (!p) return fail(GENPHI_ERR_ARG, "plan is NULL");
@@ -3514,15 +3588,25 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     // into pageable memory is staged by the runtime on ONE thread (~17 GB/s; 23 GB/s with 8
     // concurrent calls); the PCIe Gen5 link carries more than twice that.
     const size_t bytes = rows * N * sizeof(float);
+    // A FULL result is bit-symmetric (every level is: both (i, j) and (j, i) are the same Float64 expression), and the plain copy is
+    // bound by the PCIe link (55 GB/s into warm pages, 53 with first-touch page faults), so GENPHI_D2H_SYM=1 sends only the tiles on and
+    // above the diagonal across the link and lets the worker threads mirror them into the lower triangle on the host.  OPT-IN: measured
+    // at 1e5 probands (profiles/microbench/out/r04_d2h_symmetric_vs_plain_cfg4.out) it takes 440-1140 ms warm and 615-1420 ms into fresh
+    // pages against a steady 724 / 756 ms for the plain copy -- the mirror pass makes the HOST the bottleneck, and a GPU box gives the
+    // process 16 CPUs (cgroup quota): whenever the 16 workers, the Python thread and the runtime's helpers exceed it, the kernel throttles
+    // the lot.  On a host with cores to spare it is the faster path; here it is not reliably so, hence not the default.
+    bool sym = rows == N && p->res_row_begin == 0 && N >= 2 && !p->tun.d2h_pageable && p->tun.d2h_sym == 1;
     int n_thr = 1;
-    if (bytes >= (size_t(256) << 20)) {
-        n_thr = 8;
+    if (bytes >= (size_t(256) << 20) || sym) {
+        n_thr = sym ? 16 : 8;
         if (p->tun.d2h_threads > 0) n_thr = std::max(1, std::min(32, p->tun.d2h_threads));
     }
     const size_t row_bytes = N * sizeof(float);
+    const size_t tile_r = p->tun.d2h_tile_rows > 0 ? static_cast<size_t>(p->tun.d2h_tile_rows) : 256;
+    const size_t tile_c = p->tun.d2h_tile_cols > 0 ? static_cast<size_t>(p->tun.d2h_tile_cols) : 8192;
     const size_t chunk_rows = std::max<size_t>(1, (size_t(16) << 20) / row_bytes);
-    const size_t chunk_bytes = chunk_rows * row_bytes;
-    bool pinned = n_thr > 1 && !p->tun.d2h_pageable;
+    const size_t chunk_bytes = sym ? std::max<size_t>(tile_r * std::min(tile_c, N) * sizeof(float), 4096) : chunk_rows * row_bytes;
+    bool pinned = (n_thr > 1 || sym) && !p->tun.d2h_pageable;
     if (pinned && (p->pin.size() < static_cast<size_t>(2 * n_thr) || p->pin_bytes < chunk_bytes)) {
         for (void *q : p->pin) (void)hipHostFree(q);
         for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
@@ -3544,7 +3628,90 @@ int genphi_result_to_host(genphi_plan *p, float *out)
             p->pin.clear(); p->pin_streams.clear();
         }
     }
+    if (!pinned) sym = false;
     std::vector<hipError_t> errs(n_thr, hipSuccess);
+    if (sym) {
+        // items: (row block I, column tile J) with the tile's columns clipped to [max(c0, a), c1): on or right of the diagonal block
+        struct Item { uint32_t a, b, cs, c1; };
+        std::vector<Item> items;
+        for (size_t a = 0; a < N; a += tile_r) {
+            const size_t b = std::min(N, a + tile_r);
+            for (size_t c0 = a / tile_c * tile_c; c0 < N; c0 += tile_c) {
+                const size_t cs = std::max(c0, a), c1 = std::min(N, c0 + tile_c);
+                items.push_back({static_cast<uint32_t>(a), static_cast<uint32_t>(b), static_cast<uint32_t>(cs), static_cast<uint32_t>(c1)});
+            }
+        }
+        std::atomic<size_t> next{0};
+        const size_t src_pitch = static_cast<size_t>(p->res_ld) * sizeof(float);
+        const bool avx2 = __builtin_cpu_supports("avx2") != 0;
+        auto worker = [&](int t) {
+            hipError_t e = hipSetDevice(p->device);
+            if (e != hipSuccess) { errs[t] = e; return; }
+            hipStream_t st = p->pin_streams[t];
+            float *pb[2] = {static_cast<float *>(p->pin[2 * t]), static_cast<float *>(p->pin[2 * t + 1])};
+            auto issue = [&](const Item &it, float *dst) {
+                const size_t w = it.c1 - it.cs;
+                return hipMemcpy2DAsync(dst, w * sizeof(float), p->result + static_cast<size_t>(it.a) * static_cast<size_t>(p->res_ld) + it.cs, src_pitch,
+                                        w * sizeof(float), it.b - it.a, hipMemcpyDeviceToHost, st);
+            };
+            // (waits sleep instead of spinning -- a blocking-sync event per buffer: the host side is the bottleneck of this copy,
+            // and a GPU box gives a process 16 CPUs; spinning waiters take them from the threads that mirror tiles)
+            hipEvent_t evb[2] = {nullptr, nullptr};
+            for (hipEvent_t &x : evb)
+                if ((e = hipEventCreateWithFlags(&x, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) { errs[t] = e; return; }
+            size_t cur = next.fetch_add(1);
+            if (cur >= items.size()) { for (hipEvent_t x : evb) (void)hipEventDestroy(x); return; }
+            e = issue(items[cur], pb[0]);
+            if (e == hipSuccess) e = hipEventRecord(evb[0], st);
+            for (int k = 0; e == hipSuccess; ++k) {
+                e = hipEventSynchronize(evb[k & 1]);        // item `cur` has landed in pb[k & 1]
+                if (e != hipSuccess) break;
+                const size_t nxt = next.fetch_add(1);
+                if (nxt < items.size()) {                   // the DMA engine fills the other buffer meanwhile
+                    e = issue(items[nxt], pb[(k + 1) & 1]);
+                    if (e == hipSuccess) e = hipEventRecord(evb[(k + 1) & 1], st);
+                }
+                const Item it = items[cur];
+                const float *blk = pb[k & 1];
+                const size_t w = it.c1 - it.cs, nr = it.b - it.a;
+                for (size_t r = 0; r < nr; ++r)             // the tile itself
+                    std::memcpy(out + (it.a + r) * N + it.cs, blk + r * w, w * sizeof(float));
+                // its mirror image: columns right of the diagonal block become the rows' entries [a, b), 16 columns (a cache
+                // line of every tile row) at a time through a small buffer, written as runs of nr floats
+                const size_t ts = std::max<size_t>(it.cs, it.b);
+                constexpr size_t KB = 16;
+                static thread_local std::vector<float> tmp;
+                tmp.resize(KB * nr);
+                for (size_t cb0 = ts; cb0 < it.c1; cb0 += KB) {
+                    const size_t nb = std::min(KB, it.c1 - cb0);
+                    const float *src = blk + (cb0 - it.cs);
+                    if (nb == KB) {
+                        size_t r = 0;
+                        if (avx2) r = mirror_gather16_avx2(src, w, nr, tmp.data());       // 8 x 8 register transposes, whole multiples of 8 rows
+                        for (; r < nr; ++r) {
+                            const float *sr = src + r * w;
+#pragma unroll
+                            for (size_t q = 0; q < KB; ++q) tmp[q * nr + r] = sr[q];
+                        }
+                    } else {
+                        for (size_t r = 0; r < nr; ++r)
+                            for (size_t q = 0; q < nb; ++q) tmp[q * nr + r] = src[r * w + q];
+                    }
+                    for (size_t q = 0; q < nb; ++q) std::memcpy(out + (cb0 + q) * N + it.a, tmp.data() + q * nr, nr * sizeof(float));
+                }
+                if (nxt >= items.size()) break;
+                cur = nxt;
+            }
+            for (hipEvent_t x : evb) (void)hipEventDestroy(x);
+            errs[t] = e;
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t) th.emplace_back(worker, t);
+        for (auto &x : th) x.join();
+        for (hipError_t e : errs)
+            if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_to_host: ") + hipGetErrorString(e));
+        return GENPHI_OK;
+    }
     auto copy_block = [&](int t) {
         const size_t r0 = rows * t / n_thr, r1 = rows * (t + 1) / n_thr;
         if (r1 == r0) return;

@@ -591,9 +591,12 @@ static int panel_pack_impl(genphi_panel *p, int32_t step, float *d_send, bool or
         PN_TRY(hipGetLastError());
     }
     if (ordered) {
-        // (also with nothing to send: the driver's next collective overwrites the receive buffer, which the previous step's unpack reads)
-        PN_TRY(hipEventRecord(p->ev_x[0], p->stream));
-        PN_TRY(hipStreamWaitEvent(caller, p->ev_x[0], 0));
+        // (also with nothing to send: the driver's next collective overwrites the receive buffer, which the previous step's unpack reads;
+        // GENPHI_NO_STREAM: no collective follows -- one rank -- and a cross-stream wait costs ~8 us of device time each)
+        if (caller != static_cast<hipStream_t>(GENPHI_NO_STREAM)) {
+            PN_TRY(hipEventRecord(p->ev_x[0], p->stream));
+            PN_TRY(hipStreamWaitEvent(caller, p->ev_x[0], 0));
+        }
     } else if (n_send > 0) {
         PN_TRY(hipStreamSynchronize(p->stream));               // the host driver's collective runs on another stream
     }
@@ -617,7 +620,7 @@ static int panel_compute_impl(genphi_panel *p, int32_t step, const float *d_recv
     const int n_own = static_cast<int>(p->member[step].size());
     const long long ldp = pitch(static_cast<long long>(n_own) + ps.n_ext);
     float *psi = p->panel[step & 1];
-    if (ordered) {                                             // the received columns are complete on the caller's stream
+    if (ordered && caller != static_cast<hipStream_t>(GENPHI_NO_STREAM)) {      // the received columns are complete on the caller's stream
         PN_TRY(hipEventRecord(p->ev_x[1], caller));
         PN_TRY(hipStreamWaitEvent(p->stream, p->ev_x[1], 0));
     }

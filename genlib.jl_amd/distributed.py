@@ -96,7 +96,9 @@ def panel_sweep(pl, dist, dev, ordered=True):
     sent = 0
     t_begin = time.perf_counter()
     if ordered:
-        stream = torch.cuda.current_stream(dev).cuda_stream          # raw hipStream_t the collective is enqueued on
+        world = dist.get_world_size() if dist is not None else 1
+        # raw hipStream_t the collective is enqueued on; one rank: no collective, nothing to order across streams (GENPHI_NO_STREAM)
+        stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else -1
         for step, (s_cols, r_cols, cf) in enumerate(counts):
             pl.pack_on(step, sp, stream)
             _exchange(dist, send, recv, s_cols, r_cols, cf)

@@ -262,7 +262,9 @@ int genphi_panel_compute(genphi_panel *p, int32_t step, const float *d_recv);
 /* The same two calls ordered by streams instead of host synchronisations (what distributed.py uses): caller_stream is the
  * hipStream_t the host driver enqueues its collective on (torch's current stream).  pack_on makes caller_stream wait for the
  * packed columns; compute_on makes the panel's stream wait for what caller_stream holds (the collective) before it unpacks.
- * Neither blocks the host; genphi_panel_sync (or result_to_host / step_ms) waits for the sweep.                          */
+ * Neither blocks the host; genphi_panel_sync (or result_to_host / step_ms) waits for the sweep.  caller_stream =
+ * GENPHI_NO_STREAM: no collective runs between the two calls (a single rank), nothing is ordered across streams.        */
+#define GENPHI_NO_STREAM ((void *)(intptr_t)-1)
 int genphi_panel_pack_on(genphi_panel *p, int32_t step, float *d_send, void *caller_stream);
 int genphi_panel_compute_on(genphi_panel *p, int32_t step, const float *d_recv, void *caller_stream);
 int genphi_panel_sync(genphi_panel *p);

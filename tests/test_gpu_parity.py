@@ -382,6 +382,38 @@ def test_huge_sibships_through_the_split_kernels(gen, oracle, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
+def test_result_to_host_symmetric_copy(gen, oracle, monkeypatch):
+    """genphi_result_to_host of a FULL result moves only the tiles on and above the diagonal across the link and mirrors them on
+    the host (the matrix is bit-symmetric; the reference returns the full Matrix{Float32}, src/compute.jl:303): forced here on
+    small results with odd tile shapes (several column tiles per row block, ragged last tiles, tiles wider than the matrix, a
+    single thread), == the plain copy (GENPHI_D2H_SYM=0) == the oracle; row shards keep the plain copy."""
+    from genlib_jl_amd import synth
+    for args, kw in [((9000, 2501, 6), dict(skip_permille=30)), ((3000, 97, 5), dict()), ((400, 3, 4), dict())]:
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        assert np.array_equal(want, want.T)
+        for env in ({"GENPHI_D2H_SYM": "0"}, {"GENPHI_D2H_SYM": "1"}, {"GENPHI_D2H_SYM": "1", "GENPHI_D2H_TILE": "96x700", "GENPHI_D2H_THREADS": "5"},
+                    {"GENPHI_D2H_SYM": "1", "GENPHI_D2H_TILE": "33x64", "GENPHI_D2H_THREADS": "1"},
+                    {"GENPHI_D2H_SYM": "1", "GENPHI_D2H_TILE": "1000x50", "GENPHI_D2H_THREADS": "3"}):
+            for k in ("GENPHI_D2H_SYM", "GENPHI_D2H_TILE", "GENPHI_D2H_THREADS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pl = gen.plan(ped, pro)
+            for rep in range(2):
+                got = np.full_like(want, np.float32(-7.0))
+                pl.compute_device()
+                got[...] = pl.result_to_host()
+                _assert_equal(got, want)
+            n = len(want)
+            _assert_equal(pl.compute(rows=(n // 3, n)), want[n // 3:])          # a shard is not symmetric by itself: plain copy
+            _assert_equal(pl.compute(), want)
+            pl.close()
+    for k in ("GENPHI_D2H_SYM", "GENPHI_D2H_TILE", "GENPHI_D2H_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_phi_mean_on_device(gen, oracle):
     """phiMean reduced on the device (no 40 GB device-to-host copy)."""
     ped = gen.genealogy(gen.geneaJi)
