@@ -461,8 +461,17 @@ def main():
             nm = "level_naive_kernel" if args.kernel == 1 else ("levels_small_kernel" if small else names.get(modes[k], "?"))
             by_kernel[nm] = by_kernel.get(nm, 0.0) + float(t)
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else "level_split_kernel"
+        # Levels that stay IN PLACE (persistent slots) never move their dragged x dragged block (src/compute.jl:108-110 copies it):
+        # the algorithmic bytes 4 (n_k^2 + n_{k+1}^2) count it twice (read + write), so `frac` on them is no bandwidth figure and
+        # can exceed 1.  For such steps `frac` / `achieved` use the bytes the formulation still has to move, 4 (n_k^2 + n_{k+1}^2)
+        # - 8 n_dragged^2; the purely algorithmic figure stays under `algorithmic_frac`.  No in-place step: the two coincide.
+        in_place = [bool(pl.step_slots(k)[0] & 1) for k in range(len(byt))]
+        byt_alg = list(byt)
+        byt = [x - (esz * 2.0 * both[k] * both[k] if in_place[k] and not f64 and args.kernel == 0 else 0.0) for k, x in enumerate(byt)]
         tot_b, tot_ms = float(sum(byt)), float(lvl_kernel.sum())
         achieved = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        achieved_alg = float(sum(byt_alg)) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        moved_total = pl.algorithmic_bytes * esz / 4.0 - (float(sum(byt_alg)) - tot_b)      # whole sweep, the in-place blocks dropped
         # end to end through the C-ABI: plan (host) + first call (upload, allocation,
         # one sweep) ... + a sweep + the device-to-host copy of the N x N result.  Never `value`.
         end_to_end = {"plan_ms": plan_ms, "first_call_ms": first_call_ms, "sweep_ms": ms_per_step}
@@ -519,7 +528,7 @@ def main():
                        # WIDE level steps that write their cut in place (persistent slots: only new rows / columns move)
                        "in_place_steps": sum(pl.step_slots(k)[0] & 1 for k in range(max(len(sizes) - 1, 0)))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_frac": achieved_alg / HBM_PEAK_GBS, "traffic": traffic,
                          # context, not the headline: what this access pattern (whole 96 KB rows, 16-byte
                          # accesses, 3 reads : 2 writes, no reuse) can move at all on this GPU, measured by
                          # profiles/microbench/row_stream.hip; and the rate of the REAL traffic when known
@@ -536,15 +545,17 @@ def main():
                                             "frac": max(byt) / (float(lvl_kernel[int(np.argmax(byt))]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                            if len(byt) and float(lvl_kernel[int(np.argmax(byt))]) > 0 else None),
                          "algorithmic_bytes_per_launch_avg": tot_b / max(len(byt), 1),
-                         "whole_step_frac": (pl.algorithmic_bytes * esz / 4.0 / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         "whole_step_frac": (moved_total / (kernel_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if kernel_ms > 0 else None,
                          # host wall clock per sweep without per-level events (hipGraph replay for >= 8 level steps)
                          "graph_replay_ms_per_step": replay_ms,
-                         "graph_replay_frac": (pl.algorithmic_bytes * esz / 4.0 / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None},
+                         "graph_replay_frac": (moved_total / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None},
         }
         if out["config"]["in_place_steps"]:
-            out["roofline"]["frac_note"] = ("WIDE levels stay in place: the dragged x dragged block counts in the algorithmic bytes but is never "
-                                            "moved, so `frac` is not a bandwidth figure here (it can exceed 1); `real_traffic_frac` is")
+            out["roofline"]["frac_note"] = ("levels stay in place: their dragged x dragged block counts in the algorithmic bytes 4 sum(n_k^2 + n_{k+1}^2) "
+                                            "but is never moved; `frac` / `achieved` count the bytes still to be moved (that block dropped for the in-place "
+                                            "steps), `algorithmic_frac` the full formula (not a bandwidth figure: it can exceed 1), `real_traffic_frac` the "
+                                            "measured HBM traffic")
         if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
         print(json.dumps(out), flush=True)

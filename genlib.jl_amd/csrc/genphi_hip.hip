@@ -2279,6 +2279,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         if (device >= 0 && device != p->device) free_device(p);
         else { HIP_TRY(hipSetDevice(p->device)); return GENPHI_OK; }
     }
+    PhaseTrace trace;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(GENPHI_ERR_DEVICE, "no HIP device available: the gen.phi product path has no CPU fallback");
@@ -2294,6 +2295,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
     }
 
+    trace.mark("  upload: device, stream");
     const Plan &pl = p->plan;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t total = 256;
@@ -2317,7 +2319,9 @@ static int upload_plan_impl(genphi_plan *p, int device)
                      al(s.blk_slot.size() * sizeof(int)) + al((s.live_ranges.size() / 2 + static_cast<size_t>(s.stay ? s.P : 0) / 256 + 1) * sizeof(int2));
     }
     total += al(pl.final_perm.size() * sizeof(int));
+    trace.mark("  upload: walk lists (host)");
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
+    trace.mark("  upload: hipMalloc index blob");
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t pad_bytes = 0) -> char * {
@@ -2382,8 +2386,10 @@ static int upload_plan_impl(genphi_plan *p, int device)
         }
     }
     p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
+    trace.mark("  upload: host image");
     HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
+    trace.mark("  upload: copy to device");
 
     const size_t n_slots = n_all + 1;                    // queue / counter slots: one per (sub-)step
     p->n_slots = n_slots;

@@ -44,6 +44,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -300,6 +303,15 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         return genphi_set_error(GENPHI_ERR_ARG, "genphi_sparse_phi: null or negative argument");
     genphi_sparse *R = new (std::nothrow) genphi_sparse();
     if (!R) return genphi_set_error(GENPHI_ERR_ALLOC, "out of memory");
+    // GENPHI_TRACE=1: wall-clock marks of the phases of this call on stderr
+    const bool tracing = std::getenv("GENPHI_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!tracing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[genphi trace] sparse: %-24s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     auto bail = [&](int code, const std::string &msg) { delete R; return genphi_set_error(code, msg); };
 
     // ---- the pruned pedigree: probands and their ancestors, in pedigree order (branching) ----------
@@ -320,6 +332,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     }
     for (int64_t x = n_ind - 1; x >= 0; --x)                     // parents precede children: one reverse sweep
         if (keep[x]) { if (fa[x] >= 0) keep[fa[x]] = 1; if (mo[x] >= 0) keep[mo[x]] = 1; }
+    mark("id map, pruning marks");
     std::vector<int> iso_of(n_ind, -1), orig;                    // pruned index <-> original index
     for (int64_t x = 0; x < n_ind; ++x) if (keep[x]) { iso_of[x] = static_cast<int>(orig.size()); orig.push_back(static_cast<int>(x)); }
     const int m = static_cast<int>(orig.size());                 // rank of pruned index u is u + 1
@@ -374,6 +387,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     for (int k = 1; k < m; ++k)
         if (depth[order[k]] < depth[order[k - 1]]) return bail(GENPHI_ERR_ARG, "internal: processing order is not depth-sorted");
 
+    mark("children lists, queue");
     // ---- waves: active lists, parents' slots, survivors; the layout of ONE device blob of every index array ----
     auto meta_of = [&](int u) { return make_int2(2 * (u + 1) + (pro_flag[u] ? 1 : 0), proc[u]); };
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -432,6 +446,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     }
     for (double x : R->wave_bytes) R->algorithmic_bytes += x;
 
+    mark("waves, blob image");
     // ---- the device sweep: every launch of every wave in stream order, one synchronisation at the end ------
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -464,6 +479,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         SP_GO(hipMalloc(reinterpret_cast<void **>(&d_sval), static_cast<size_t>(stale_cap) * sizeof(float)));
         SP_GO(hipMalloc(reinterpret_cast<void **>(&d_src), static_cast<size_t>(stale_cap) * sizeof(int2)));
         SP_GO(hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(int)));
+        mark("stream, 7 allocations");
         SP_GO(hipMemcpyAsync(d_blob, blob.data(), blob_bytes, hipMemcpyHostToDevice, st));
         SP_GO(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
         if (max_lds > 48 * 1024)
@@ -504,8 +520,10 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             cur ^= 1;
             ld_cur = ld_next;
         }
+        mark("upload + enqueue");
         SP_GO(hipMemcpyAsync(&n_stale, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
         SP_GO(hipStreamSynchronize(st));
+        mark("sweep done");
         if (n_stale > stale_cap) {                                // more entries outlive their columns than the list holds: once more, sized exactly
             if (attempt == 1 || n_stale > (1 << 28)) { cleanup(); return bail(GENPHI_ERR_ALLOC, "genphi_sparse_phi: too many entries outlive their columns"); }
             stale_cap = n_stale;
@@ -535,7 +553,9 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             R->wave_ms.resize(waves.size());
             for (size_t wi = 0; wi < waves.size(); ++wi) SP_GO(hipEventElapsedTime(&R->wave_ms[wi], ev[wi], ev[wi + 1]));
         }
+        mark("results to host");
         cleanup();
+        mark("free");
         break;
     }
 #undef SP_GO

@@ -153,3 +153,43 @@ def test_rccl_communicator_at_one_rank():
     # no host synchronisation inside a sweep: the wall time of a sweep is the kernels' time plus little
     per_rank = d["roofline"]["per_rank_kernels"]
     assert d["ms_per_step"] <= 1.35 * per_rank["device_ms_per_sweep"] + 0.15, (d["ms_per_step"], per_rank)
+
+
+def test_survey_literal_cfg4_needs_panels_and_fits_eight_ranks():
+    """SURVEY.md 8(d)'s cfg4 taken literally (5 % of the parents from generation g-2): cuts to 206,808 members, B = 3.74 TB -- the
+    north star's "N exceeds one GPU's HBM" case.  Host-side only: the replicated path does not fit 288 GB, a column panel at world = 8
+    does with a wide margin, every rank's exchange volume and the largest step's are what DESIGN.md 6.2 tabulates (so that the first
+    8-GPU lease is a measurement, not a debugging session): ~66 GB sent per rank and sweep, <= 4.1 GB in one step, i.e. ~61 ms of
+    xGMI time per sweep at 7 links x 153 GB/s when the peers are evenly loaded."""
+    sys.path.insert(0, ROOT)
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth, _capi, distributed as gdist
+    ind, fa, mo, sex, pro = synth.random_mating(1_000_000, 100_000, 30, skip_permille=50)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    sizes, both = pl.levels()
+    assert max(sizes) == 206_808 and 3.7e12 < pl.algorithmic_bytes < 3.8e12
+    pl.close()
+    hbm = 288e9
+    assert not gdist.replicated_levels_fit(sizes, hbm, both_counts=both)        # two level matrices of 2e5 members: 340 GB
+    world = 8
+    sent = []
+    for r in (0, 5):
+        pp = _capi.PanelPlan(ped.ind, ped.father, ped.mother, pro, r, world)
+        assert pp.device_bytes < 0.25 * hbm, pp.device_bytes                   # 54.7 GB per rank, result block included
+        assert pp.result_rows() == (12_500 * r, 12_500)
+        assert set(pp.step_modes()) <= {0, 1}                                  # every step through the row kernels (panel rows fit in LDS)
+        tot, worst = 0, 0
+        for step in range(pp.n_steps):
+            s_cols, r_cols, cf = pp.exchange_counts(step)
+            assert s_cols[r] == 0 and r_cols[r] == 0
+            tot += int(s_cols.sum()) * cf * 4
+            worst = max(worst, int(s_cols.sum()) * cf * 4, int(r_cols.sum()) * cf * 4)
+            # evenly loaded peers: no peer gets more than twice the mean share of a step that moves something real
+            if s_cols.sum() > 7000:
+                assert s_cols.max() <= 2 * s_cols.sum() / (world - 1)
+        sent.append(tot)
+        assert 60e9 < tot < 70e9 and worst < 4.2e9
+        pp.close()
+    xgmi_s = max(sent) / (7 * 153e9)
+    assert 0.055 < xgmi_s < 0.066
