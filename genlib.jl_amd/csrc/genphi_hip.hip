@@ -2306,13 +2306,33 @@ static int upload_plan_impl(genphi_plan *p, int device)
     const size_t n_main = pl.steps.size(), n_all = n_main + p->nn_steps.size();
     auto step_at = [&](size_t k) -> const LevelStep & { return k < n_main ? pl.steps[k] : *p->nn_steps[k - n_main]; };
     std::vector<GroupLists> step_groups(n_all);
+    {   // the hub walks of the SPLIT steps are independent of each other: a few host threads (24 -> ~7 ms of a first call on cfg4)
+        std::vector<size_t> split_steps;
+        for (size_t k = 0; k < n_all; ++k) if (step_at(k).mode == genphi::kModeSplit) split_steps.push_back(k);
+        std::sort(split_steps.begin(), split_steps.end(), [&](size_t a, size_t b) { return step_at(a).n > step_at(b).n; });      // the big last step first
+        const int n_thr = static_cast<int>(std::min<size_t>(4, split_steps.size()));
+        std::atomic<size_t> next{0};
+        std::vector<char> oom(std::max(n_thr, 1), 0);
+        auto work = [&](int t) {
+            try {
+                for (size_t q = next.fetch_add(1); q < split_steps.size(); q = next.fetch_add(1)) {
+                    const LevelStep &s = step_at(split_steps[q]);
+                    build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[split_steps[q]], p->tun);
+                }
+            } catch (const std::bad_alloc &) { oom[t] = 1; }
+        };
+        if (n_thr <= 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (char e : oom) if (e) return fail(GENPHI_ERR_ALLOC, "out of memory while building the work lists");
+    }
     for (size_t k = 0; k < n_all; ++k) {
         const LevelStep &s = step_at(k);
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
-        if (s.mode == genphi::kModeSplit) {
-            build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), step_groups[k], p->tun);
-            total += groups_bytes(step_groups[k]);
-        }
+        if (s.mode == genphi::kModeSplit) total += groups_bytes(step_groups[k]);
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +

@@ -333,6 +333,27 @@ def test_wide_cuts_at_real_size_default_settings(gen, oracle):
     pl.close()
 
 
+def test_wide_in_place_at_real_size_default_settings(gen, oracle):
+    """In-place levels at WIDE width against the ORACLE with no test hook: 1.5e5 individuals / 8,000 probands / 12 generations,
+    20 % of the parents from g-2 -- cuts to 42,298 members (a source row does not fit in LDS), six steps in place, three of them
+    on cuts wider than 36,864, the rest of the run at SPLIT width; bit for bit (4.1e9 pair evaluations on the host, ~40 s), plus
+    a row shard and the per-entry kernel sweep on the same plan."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(150_000, 8_000, 12, skip_permille=200)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    sizes, both = pl.levels()
+    flags = [pl.step_slots(k) for k in range(len(sizes) - 1)]
+    stay = [k for k, f in enumerate(flags) if f[0] & 1]
+    assert max(sizes) > 36_864 and len(stay) >= 5 and sum(sizes[k] > 36_863 for k in stay) >= 3, (sizes, flags)
+    want = oracle.Pedigree(ind, fa, mo).phi(pro)
+    for rep in range(3):
+        _assert_equal(pl.compute(), want)
+    _assert_equal(pl.compute(rows=(1_000, 1_900)), want[1_000:1_900])
+    _assert_equal(pl.compute(kernel=1), want)
+    pl.close()
+
+
 def test_many_probands_from_few_parents(gen, oracle, monkeypatch):
     """A final level much wider than the cut above it (1100 parents, 20 000 probands: 18 children per
     parent): the FULL kernel walks 20 000 columns per row from two 4.4 KB source rows; the same pedigree
