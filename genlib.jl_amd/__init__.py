@@ -218,10 +218,9 @@ def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, ker
         if not compute:
             return None
         if verbose:
-            # the reference prints these inside the level loop; the GPU sweep is one blocking
-            # call, so they are printed just before it
-            for k in range(nsteps):
-                print(f"Running step {k + 1} of {nsteps} ({sizes[k]} founders, {sizes[k + 1]} probands, {both[k]} both).")
+            # the reference prints these inside its level loop (src/compute.jl:280-285): the library calls back right before it
+            # hands each level step to the GPU
+            pl.set_step_hook(lambda k, n: print(f"Running step {k + 1} of {n} ({sizes[k]} founders, {sizes[k + 1]} probands, {both[k]} both).", flush=True))
         return pl.compute(device=device, kernel=kernel)
     finally:
         pl.close()

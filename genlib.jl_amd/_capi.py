@@ -27,6 +27,9 @@ _I64P = C.POINTER(C.c_int64)
 _F32P = C.POINTER(C.c_float)
 
 
+STEP_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)      # genphi_step_fn
+
+
 class GenphiOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("kernel", C.c_int32), ("row_begin", C.c_int64),
                 ("row_end", C.c_int64), ("timing", C.c_int32), ("flags", C.c_int32)]
@@ -41,7 +44,7 @@ class GenphiStats(C.Structure):
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
-    "genphi_plan_algorithmic_bytes", "genphi_plan_step_walk", "genphi_compute_device", "genphi_result_device",
+    "genphi_plan_algorithmic_bytes", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
@@ -88,6 +91,8 @@ def lib():
         # (every symbol is bound unconditionally: this binding needs the build it was written for -- include/genphi.h)
         L.genphi_plan_step_walk.argtypes = [C.c_void_p, C.c_int32, _I64P, _I64P, _I64P, _I32P, _I32P, _I32P]
         L.genphi_plan_step_walk.restype = C.c_int
+        L.genphi_plan_set_step_hook.argtypes = [C.c_void_p, STEP_FN, C.c_void_p]
+        L.genphi_plan_set_step_hook.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -310,6 +315,14 @@ class PhiPlan:
         if rc:
             _raise(rc)
         return desc, seg, run
+
+    def set_step_hook(self, fn):
+        """fn(step, n_steps) is called right before each level step of a Float32 sweep is handed to the GPU (the reference prints
+        its "Running step ..." lines there, src/compute.jl:280-285); None removes the hook."""
+        self._hook = STEP_FN(lambda step, n, user: fn(int(step), int(n))) if fn is not None else STEP_FN()
+        rc = lib().genphi_plan_set_step_hook(self._h, self._hook, None)
+        if rc:
+            _raise(rc)
 
     def step_modes(self):
         """Kernel family per level step: 0 FULL, 1 SPLIT, 2 WIDE."""

@@ -1278,9 +1278,16 @@ transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict_
 // (A, B, output row = slot, scale).  Source and destination are the same matrix: the tile's rows and the new columns hold no
 // member of the source cut.  Certificates of both the new rows and the rows c.
 constexpr int kFT = 256;
-__global__ void __launch_bounds__(256)
+// rows of a wave's share whose parent-row loads are in flight together (2 x 16-byte loads per row and lane).  With the tile in LDS the
+// kernel runs two waves per SIMD, so the bytes in flight have to come from each wave: same-box A/B, cfg3s 3.56 / 3.40 / 3.42 ms and
+// cfg4o 155.4 / 148.8 / 147.9 ms at 4 / 8 / 16 rows (profiles/microbench/out/r04_ab_rows_avg_t_rows_in_flight_*.out)
+#ifndef GENPHI_AVG_T_ROWS
+#define GENPHI_AVG_T_ROWS 16
+#endif
+// (LDS holds the kernel to two workgroups = two waves per SIMD anyway: let the compiler use the registers of that occupancy)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ rowdesc, int n_new, const int *__restrict__ blk_slot,
-                  const int2 *__restrict__ tiles, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest)
+                  const int2 *__restrict__ tiles, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest, int scalar_t)
 {
     extern __shared__ float tile_dyn[];                          // [64][kFT + 1]
     float (*tile)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(tile_dyn);
@@ -1294,21 +1301,22 @@ rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = c0 + lane * 4;                                // this lane's four columns (ranges are multiples of 64 columns)
     const bool in = c < c_hi;
-    // ---- new x dragged: 16 rows per wave, four at a time (eight 16-byte loads in flight) ----
-    for (int r0 = w * 16; r0 < w * 16 + 16; r0 += 4) {
-        int4 d[4];
-        f4_t a[4], b[4];
+    // ---- new x dragged: 16 rows per wave, RB at a time (2 RB 16-byte loads in flight per lane) ----
+    constexpr int RB = GENPHI_AVG_T_ROWS;
+    for (int r0 = w * 16; r0 < w * 16 + 16; r0 += RB) {
+        int4 d[RB];
+        f4_t a[RB], b[RB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RB; ++u) {
             d[u] = rowdesc[g * 64 + min(r0 + u, rows_here - 1)];
             const int cc = in ? c : c_lo;                        // (clamped: unconditional loads)
             a[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].x * ld + cc);
             b[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].y * ld + cc);       // ("none" is the all-zero row)
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const int r = r0 + u;
-            if (r >= rows_here) break;                           // (wave-uniform)
+            if (r >= rows_here) continue;                        // (wave-uniform; `continue`, not `break`: the loop must unroll, d / a / b are registers)
             const double sc = d[u].w == 0 ? 1.0 : 0.5;
             f4_t v;
             unsigned ck = 0xffffffffu;
@@ -1326,13 +1334,29 @@ rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ row
     }
     __syncthreads();
     // ---- dragged x new: column k of the tile is a 256-byte run of row c0 + k ----
-    const int tx = lane;
-    for (int k = w; k < kFT; k += 4) {
-        const int cr = c0 + k;
-        if (cr < c_hi && tx < rows_here) {
-            const float v = tile[tx][k];
-            m[(long long)cr * ld + base + tx] = v;
-            if (cert_out && cert_key(v) < cert_thresh) cert_out[cr] = 1;
+    if (rows_here == 64 && !scalar_t) {
+        // 16-byte stores: a lane takes four consecutive new members (tile rows 4 q .. 4 q + 3) of one destination row, sixteen lanes
+        // cover the row's 256-byte run, a wave four destination rows per instruction
+        const int q = lane & 15, sub = lane >> 4;
+        for (int k = w * 4 + sub; k < kFT; k += 16) {
+            const int cr = c0 + k;
+            if (cr < c_hi) {
+                f4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tile[4 * q + e][k];
+                *reinterpret_cast<f4_t *>(m + (long long)cr * ld + base + 4 * q) = v;
+                if (cert_out && min(min(cert_key(v[0]), cert_key(v[1])), min(cert_key(v[2]), cert_key(v[3]))) < cert_thresh) cert_out[cr] = 1;
+            }
+        }
+    } else {
+        const int tx = lane;
+        for (int k = w; k < kFT; k += 4) {
+            const int cr = c0 + k;
+            if (cr < c_hi && tx < rows_here) {
+                const float v = tile[tx][k];
+                m[(long long)cr * ld + base + tx] = v;
+                if (cert_out && cert_key(v) < cert_thresh) cert_out[cr] = 1;
+            }
         }
     }
     (void)none;
@@ -1894,6 +1918,7 @@ struct Tuning {
     int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour); 2 = in place wherever the ratio test allows, whatever the cost model says
     int stay_family = -1;          // GENPHI_STAY_FAMILY      A/B: 0 = new members of a leaving class in rank order instead of by family
     int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
+    bool stay_scalar_t = false;    // GENPHI_STAY_SCALAR_T    A/B: the fused kernel writes its transposed tile with 4-byte stores (the round-3 form) instead of 16-byte ones
     bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
     bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
     bool stay_scatter = false;     // GENPHI_STAY_SCATTER     A/B + test: the new x new block of an in-place step always goes through the compact buffer
@@ -1936,6 +1961,7 @@ static Tuning tuning_from_env()
     t.stay_scatter = geti("GENPHI_STAY_SCATTER", 0) != 0;
     t.stay_two_pass = geti("GENPHI_STAY_TWO_PASS", 0) != 0;
     t.stay_col_fastest = geti("GENPHI_STAY_COL_FASTEST", 0) != 0;
+    t.stay_scalar_t = geti("GENPHI_STAY_SCALAR_T", 0) != 0;
     t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.stay_min_ratio_pct = geti("GENPHI_STAY_MIN_RATIO_PCT", -1);
     t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
@@ -2086,6 +2112,8 @@ struct genphi_plan {
     // product sweep (the entry cut of its in-place run; c itself otherwise).
     std::vector<int> buf_of[2], cert_cut;
     bool stay_active = false;                    // this sweep keeps WIDE levels in place (set per compute call)
+    genphi_step_fn step_hook = nullptr;          // genphi_plan_set_step_hook: called before every level step of a Float32 sweep
+    void *step_hook_user = nullptr;
     float *result = nullptr, *final_tmp = nullptr;
     // Float64-storage sweeps (gen.f, pairwise phi): own level matrices and result
     double *buf64[2] = {nullptr, nullptr}, *result64 = nullptr;
@@ -2230,6 +2258,12 @@ int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
     return GENPHI_OK;
 }
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
+int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user)
+{
+    if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
+    plan->step_hook = cb; plan->step_hook_user = user;
+    return GENPHI_OK;
+}
 
 int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows, int64_t *n_segs, int64_t *n_runs, int32_t *desc4,
                           int32_t *seg4, int32_t *run4)
@@ -2989,7 +3023,7 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
                 const unsigned nct = static_cast<unsigned>(d.n_tiles);
                 dim3 gt(gf ? static_cast<unsigned>(n_gran) : nct, gf ? nct : static_cast<unsigned>(n_gran));
                 hipLaunchKernelGGL(rows_avg_t_kernel, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
-                                   d.blk_slot, d.tiles, cert_out, thr, gf);
+                                   d.blk_slot, d.tiles, cert_out, thr, gf, p->tun.stay_scalar_t ? 1 : 0);
                 HIP_TRY(hipGetLastError());
             }
             return GENPHI_OK;
@@ -3396,6 +3430,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 const LevelStep &st = pl.steps[s];
                 const float *psi = p->buf[bid[s]];
                 const bool last = s == n_steps - 1;
+                if (p->step_hook) p->step_hook(s, n_steps, p->step_hook_user);
                 // a run of >= 2 small intermediate steps goes through ONE launch (levels_small_kernel)
                 if (kernel == 0 && !small_off) {
                     int e = s;
@@ -3414,6 +3449,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                             HIP_TRY(hipEventRecord(p->events[e], p->stream));
                             for (int k = s; k < e; ++k) ev_after[k] = e;
                         }
+                        if (p->step_hook) for (int k = s + 1; k < e; ++k) p->step_hook(k, n_steps, p->step_hook_user);      // (the steps the fused run covers)
                         s = e - 1;
                         continue;
                     }
@@ -3475,7 +3511,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     const bool graphs_off = p->tun.no_graph;
     const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0, p->alloc_gen};
     const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
-    const bool use_graph = !timing && !graphs_off && !(opts && (opts->flags & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8;
+    const bool use_graph = !timing && !graphs_off && !(opts && (opts->flags & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8 && !p->step_hook;
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
     if (use_graph) {
         if (!p->graph_exec || std::memcmp(key, p->graph_key, sizeof(key)) != 0) {

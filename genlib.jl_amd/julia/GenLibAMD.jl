@@ -75,15 +75,17 @@ function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(ped
             end
         end
         compute || return nothing                        # src/compute.jl:264-266
-        if verbose                                       # lines of src/compute.jl:281-284
-            for k in 1:nsteps
-                println("Running step $k of $nsteps ($(cut[k]) founders, $(cut[k+1]) probands, $(dragged[k]) both).")
-            end
+        hook = nothing
+        if verbose                                       # lines of src/compute.jl:281-284, printed INSIDE the level loop as there:
+            # the library calls back right before it hands each level step to the GPU (genphi_plan_set_step_hook)
+            hook = @cfunction($((step, n, _) -> (println("Running step $(step + 1) of $n ($(cut[step+1]) founders, $(cut[step+2]) probands, $(dragged[step+1]) both."); nothing)),
+                              Cvoid, (Int32, Int32, Ptr{Cvoid}))
+            check(ccall((:genphi_plan_set_step_hook, libgenphi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), plan[], hook, C_NULL))
         end
         N = Int(ccall((:genphi_plan_n_probands, libgenphi), Int64, (Ptr{Cvoid},), plan[]))
         Φ = Matrix{Float32}(undef, N, N)                 # symmetric: row-major == column-major
         opts = Ref(GenphiOpts(Int32(device), 0, 0, 0, 0, 0))
-        GC.@preserve Φ check(ccall((:genphi_compute_f32, libgenphi), Cint,
+        GC.@preserve Φ hook check(ccall((:genphi_compute_f32, libgenphi), Cint,
                                    (Ptr{Cvoid}, Ptr{Float32}, Ptr{GenphiOpts}, Ptr{Cvoid}),
                                    plan[], Φ, opts, C_NULL))
         return Φ

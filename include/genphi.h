@@ -118,6 +118,13 @@ int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
 int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows, int64_t *n_segs, int64_t *n_runs,
                           int32_t *desc4, int32_t *seg4, int32_t *run4);
 
+/* Progress hook for the "Running step k of n (...)" lines the reference prints INSIDE its level loop (src/compute.jl:280-285, verbose):
+ * cb(step, n_steps, user) is called on the calling thread right before level step `step` (0-based) is handed to the GPU, in order.
+ * While a hook is set the sweep is enqueued launch by launch (never replayed from a captured graph).  cb = NULL removes it.
+ * The hook must not call back into the library with the same plan.                                                              */
+typedef void (*genphi_step_fn)(int32_t step, int32_t n_steps, void *user);
+int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user);
+
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);
 

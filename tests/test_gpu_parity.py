@@ -589,6 +589,35 @@ def test_graph_replay_matches_eager(gen, oracle):
     pl.close()
 
 
+def test_step_hook_is_called_before_every_level_step(gen, oracle, capsys):
+    """genphi_plan_set_step_hook: the reference prints "Running step k of n (...)" INSIDE its level loop (src/compute.jl:280-285);
+    the library calls the hook right before it hands each level step to the GPU -- every step once, in order, also for the steps a
+    fused small-level run covers and on repeated sweeps (a hooked sweep is never replayed from a graph); results unchanged."""
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.deep_inbred(40, 30, 3)
+    ref = oracle.Pedigree(ind, fa, mo).phi(pro)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro)
+    n_steps = len(pl.levels()[0]) - 1
+    seen = []
+    pl.set_step_hook(lambda k, n: seen.append((k, n)))
+    for rep in range(3):
+        _assert_equal(pl.compute(), ref)
+    assert seen == [(k, n_steps) for k in range(n_steps)] * 3
+    pl.set_step_hook(None)
+    _assert_equal(pl.compute(), ref)
+    assert len(seen) == 3 * n_steps
+    pl.close()
+    # the Python mirror prints the reference's lines through it
+    ped = gen.genealogy(gen.geneaJi)
+    gen.phi(ped, verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert out[:7] == [f"Step {i} of 7: {a} founders, {b} probands, {c} both." for i, (a, b, c) in
+                       enumerate([(2, 4, 2), (4, 6, 4), (6, 7, 4), (7, 9, 4), (9, 8, 0), (8, 4, 0), (4, 3, 0)], 1)]
+    assert out[7:] == [f"Running step {i} of 7 ({a} founders, {b} probands, {c} both)." for i, (a, b, c) in
+                       enumerate([(2, 4, 2), (4, 6, 4), (6, 7, 4), (7, 9, 4), (9, 8, 0), (8, 4, 0), (4, 3, 0)], 1)]
+
+
 def test_full_size_cfg4_properties(gen):
     """BASELINE.json's headline size (1e6 individuals / 1e5 probands / 30 generations): far too
     big for the oracle, so check size-independent properties of the 40 GB result without moving
