@@ -1526,11 +1526,12 @@ level_full64_kernel(const double *__restrict__ psi, long long ld_prev, int n_pre
 
 // Float64 storage, cuts whose rows fit in LDS one at a time (8 bytes x (n_prev + 1) <= 160 KB: up to 20,479 members): the SPLIT
 // kernels' shape in its simplest form.  A workgroup walks a contiguous piece of the row list (rows sharing the A source are
-// adjacent in a step's work order) for one chunk of 512 x 12 columns: row A is staged and its terms (a, b) of the chunk's columns
+// adjacent in a step's work order) for one chunk of 512 x 14 columns: row A is staged and its terms (a, b) of the chunk's columns
 // kept in registers for as long as the following rows share it; every row with a B source stages that row, gathers (c, d), combines
 // with the reference's grouping and stores.  The next row to stage is in flight into registers behind the gathers.  Same arguments
 // as level_full64_kernel.
-constexpr int kS64Cols = 12;      // columns per thread and chunk (registers: 7 per column + the 80 of the row in flight)
+constexpr int kS64Cols = 14;      // columns per thread and chunk (registers: 7 per column + the 80 of the row in flight: 246 VGPRs, no scratch; 16 spills).
+                                  // 14 instead of round 3's 12: genea140's widest cuts (13.7k columns) take 2 chunks instead of 3, i.e. a third fewer stagings
 constexpr int kS64Pre = 20;       // d2_t pieces per source row and thread: 20,480 / 2 / 512
 __global__ void __launch_bounds__(512)
 level_split64_kernel(const double *__restrict__ psi, long long ld_prev, int n_prev, double *__restrict__ out, long long ld,
