@@ -96,6 +96,7 @@ def cpu_baseline(ped, pro, sizes, budget_s=20.0):
     source matrix) on the real index structure of that step.  Extrapolated to the whole sweep by (i <= j) kernel evaluations,
     the upper steps at the rate of (i), the last one at the rate of (ii)."""
     from oracle import oracle as O
+    O.fit_threads_to_quota()                                   # (`cores` below = the threads actually used: the CPUs the container may use)
     oped = O.Pedigree(ped.ind, ped.father, ped.mother, sort=False)
     n_pro = sizes[-1]
     evals_upper = sum(n * (n + 1) // 2 for n in sizes[1:-1])

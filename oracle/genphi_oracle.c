@@ -478,6 +478,16 @@ float oracle_phi_mean(const float *phi, int64_t n) {
     return total / (float)(n * n - n);
 }
 
+/* Threads of the level loops from here on (bench.py / the tests size it to the CPUs the process may actually use: a container
+ * with a CPU quota below the machine's core count is throttled, not sped up, by one thread per core). */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -58,6 +58,8 @@ def lib():
         L.oracle_phi_mean.argtypes = [_F32P, C.c_int64]
         L.oracle_phi_mean.restype = C.c_float
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_set_num_threads.restype = None
         _LIB = L
     return _LIB
 
@@ -284,6 +286,36 @@ def phi_mean(phi):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box gives a container 16 of its
+    256 hardware threads: `cpu.max` = "1600000 100000"); one OpenMP thread per hardware thread is throttled there, not sped up."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def fit_threads_to_quota():
+    """Sets the oracle's OpenMP thread count to usable_cpus() when that is fewer than the default; returns the threads in use."""
+    n = usable_cpus()
+    if n < num_threads():
+        lib().oracle_set_num_threads(n)
+    return num_threads()
 
 
 _SLIB = None
