@@ -18,6 +18,7 @@ def main():
     from genlib_jl_amd import synth
     from genlib_jl_amd.distributed import phi_panels
     from oracle import oracle as O
+    O.fit_threads_to_quota()
     torch.cuda.set_device(0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:

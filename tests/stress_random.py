@@ -80,6 +80,7 @@ def main():
     import genlib_jl_amd as gen
     from genlib_jl_amd import synth
     from oracle import oracle as O
+    O.fit_threads_to_quota()
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed0)
