@@ -1004,10 +1004,10 @@ def test_narrow_levels_stay_in_place(gen, oracle, monkeypatch):
         ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
         want = oracle.Pedigree(ind, fa, mo).phi(pro)
         knobs = ("GENPHI_CERT_MIN_EXP", "GENPHI_NO_FAST", "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-                 "GENPHI_STAY_NARROW", "GENPHI_STAY_SLACK_PCT", "GENPHI_FULL_MAX_FLOATS")
+                 "GENPHI_STAY_NARROW", "GENPHI_STAY_SLACK_PCT", "GENPHI_FULL_MAX_FLOATS", "GENPHI_STAY_SCALAR_T")
         for env in ({}, {"GENPHI_CERT_MIN_EXP": "-4"}, {"GENPHI_NO_FAST": "1"}, {"GENPHI_STAY_HEADROOM": "2", "GENPHI_CERT_MIN_EXP": "-4"},
                     {"GENPHI_STAY_SCATTER": "1"}, {"GENPHI_STAY_TWO_PASS": "1", "GENPHI_CERT_MIN_EXP": "-6"}, {"GENPHI_STAY_SLACK_PCT": "0"},
-                    {"GENPHI_FULL_MAX_FLOATS": "0"}, {"GENPHI_STAY_NARROW": "0"}):
+                    {"GENPHI_FULL_MAX_FLOATS": "0"}, {"GENPHI_STAY_SCALAR_T": "1"}, {"GENPHI_STAY_NARROW": "0"}):
             for k in knobs:
                 monkeypatch.delenv(k, raising=False)
             monkeypatch.setenv("GENPHI_STAY_NARROW_MIN", str(nmin))
