@@ -1918,6 +1918,8 @@ struct Tuning {
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
     int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour); 2 = in place wherever the ratio test allows, whatever the cost model says
     int stay_family = -1;          // GENPHI_STAY_FAMILY      A/B: 0 = new members of a leaving class in rank order instead of by family
+    int stay_overhead_k = -1;      // GENPHI_STAY_OVERHEAD_K  tuning + test: fixed cost of a block-assembled step in the planner's cost model, in thousands of
+                                   //                         matrix entries (default 64000; tests that put tiny cuts in place set 0)
     int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
     bool stay_scalar_t = false;    // GENPHI_STAY_SCALAR_T    A/B: the fused kernel writes its transposed tile with 4-byte stores (the round-3 form) instead of 16-byte ones
     bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
@@ -1967,6 +1969,7 @@ static Tuning tuning_from_env()
     t.stay_min_ratio_pct = geti("GENPHI_STAY_MIN_RATIO_PCT", -1);
     t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
     t.stay_narrow_min = geti("GENPHI_STAY_NARROW_MIN", -1);
+    t.stay_overhead_k = geti("GENPHI_STAY_OVERHEAD_K", -1);
     t.stay_family = geti("GENPHI_STAY_FAMILY", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
@@ -2201,6 +2204,7 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.stay_max_slots > 0) p->popt.stay_max_slots = p->tun.stay_max_slots;
     if (p->tun.stay_narrow >= 0) { p->popt.stay_narrow = p->tun.stay_narrow != 0; p->popt.stay_narrow_force = p->tun.stay_narrow == 2; }
     if (p->tun.stay_narrow_min >= 0) p->popt.stay_narrow_min = p->tun.stay_narrow_min;
+    if (p->tun.stay_overhead_k >= 0) p->popt.stay_step_overhead = 1000.0 * p->tun.stay_overhead_k;
     if (p->tun.stay_family >= 0) p->popt.stay_family_order = p->tun.stay_family != 0;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     if (p->tun.stay_mem_pct > 0) { p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0; p->popt.stay_mem_floor_bytes = 0.0; }   // (an explicit share is taken literally)

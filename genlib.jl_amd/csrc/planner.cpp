@@ -412,9 +412,14 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         auto nnew = [&](int32_t c) { return static_cast<double>(new_of[c].size()); };
         auto ndrag = [&](int32_t c) { return static_cast<double>(size_of[c]) - nnew(c); };
         // entries moved by the step that produces cut c: as a row-kernel level (every row staged and written whole) ...
+        // (+ a fixed cost per step in the same unit: a row-kernel level is one or two launches, a block-assembled one six to eight
+        // short ones -- clearing, Psi_P, padding, the sub-step's kernels, scatter, the new rows' pass -- about 50 us against 8, i.e.
+        // ~64M against ~10M entries at 5 TB/s.  Without it the byte counts alone put cuts of 3-6k members in place, measured 11-45 %
+        // SLOWER than their row kernels: profiles/microbench/out/r04_narrow_in_place_planner_choice.out)
+        const double ov_rows = 0.15 * opt.stay_step_overhead, ov_blk = opt.stay_step_overhead;
         auto cost_rows = [&](int32_t c) {
             const double np = static_cast<double>(size_of[c - 1]), n = static_cast<double>(size_of[c]);
-            return (ndrag(c) + 1.5 * nnew(c)) * np + n * n;
+            return (ndrag(c) + 1.5 * nnew(c)) * np + n * n + ov_rows;
         };
         // ... the blocks that involve new members, common to both forms of block assembly (Psi_P, the new x new sub-step) ...
         auto cost_nn = [&](int32_t c) {
@@ -424,10 +429,10 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         // ... assembled compactly (every row re-written at the dragged columns, the transposed block) ...
         auto cost_blk = [&](int32_t c) {
             const double np = static_cast<double>(size_of[c - 1]), n = static_cast<double>(size_of[c]);
-            return cost_nn(c) + (ndrag(c) + 2.0 * nnew(c)) * np + n * ndrag(c) + 2.0 * nnew(c) * ndrag(c);
+            return cost_nn(c) + (ndrag(c) + 2.0 * nnew(c)) * np + n * ndrag(c) + 2.0 * nnew(c) * ndrag(c) + ov_blk;
         };
         // ... in place (only the new rows and columns move; the new x new block may go through the scatter buffer)
-        auto cost_stay = [&](int32_t c) { return cost_nn(c) + nnew(c) * nnew(c) + 3.5 * nnew(c) * ndrag(c); };
+        auto cost_stay = [&](int32_t c) { return cost_nn(c) + nnew(c) * nnew(c) + 3.5 * nnew(c) * ndrag(c) + ov_blk; };
         for (int32_t c = 2; c + 1 < L; ++c) {
             const bool by_width = blk[c] && blk[c + 1];                  // both steps assemble blocks anyway
             const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min && c + 2 < L &&      // (the reader is never the proband step)

@@ -113,6 +113,8 @@ struct PlanOptions {
     int32_t stay_slack_pct = 6;       // free slots a run starts with beyond its widest (cut + new members), in % (granules that are only partly dead)
     bool stay_narrow = true;          // cuts whose rows fit in LDS (FULL / SPLIT widths) may stay in place too: their steps are switched to block
                                       // assembly when the cost model says the dragged x dragged copy that is saved outweighs the extra passes
+    double stay_step_overhead = 64e6;  // fixed cost of a block-assembled step in the cost model, in matrix entries (its six to eight short launches; a row-kernel
+                                      // level is charged 15 % of it); tests that put tiny cuts in place set it to 0
     bool stay_narrow_force = false;   // A/B hook: ... whatever the cost model says (every step that passes the ratio test)
     int64_t stay_narrow_min = 2048;   // ... from this width of the source cut on (narrower levels are bound by their launches, not their bytes)
     bool stay_family_order = true;    // new members of a cut of an in-place plan: siblings (same father) adjacent inside a leaving class

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T"]
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K"]
 
 
 def make_case(case):
@@ -67,6 +67,7 @@ def make_case(case):
     # in-place runs at FULL / SPLIT widths (round 4): the cost model decides per run; small pedigrees need the width floor lowered
     if r.random() < 0.65:
         env["GENPHI_STAY_NARROW_MIN"] = str(int(r.choice([0, 16, 64, 200])))
+        env["GENPHI_STAY_OVERHEAD_K"] = "0"                                       # (the cost model on bytes alone: tiny cuts would never pay a step's launches)
     elif r.random() < 0.3:
         env["GENPHI_STAY_NARROW"] = "0"
     if r.random() < 0.3:

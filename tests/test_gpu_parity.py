@@ -1011,6 +1011,7 @@ def test_narrow_levels_stay_in_place(gen, oracle, monkeypatch):
             for k in knobs:
                 monkeypatch.delenv(k, raising=False)
             monkeypatch.setenv("GENPHI_STAY_NARROW_MIN", str(nmin))
+            monkeypatch.setenv("GENPHI_STAY_OVERHEAD_K", "0")      # (bytes only: the launch overhead term would keep these small cuts on their row kernels)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             pl = gen.plan(ped, pro)
@@ -1043,7 +1044,7 @@ def test_narrow_levels_stay_in_place(gen, oracle, monkeypatch):
                 _assert_equal(pl.compute(), want)
             pl.close()
     assert stays >= 300
-    for k in knobs + ("GENPHI_STAY_NARROW_MIN",):
+    for k in knobs + ("GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_OVERHEAD_K"):
         monkeypatch.delenv(k, raising=False)
     # a real genealogy: the cost model keeps genea140's row kernels (36-46 % of the members of its wide cuts are new); lowering
     # the bar (a cut needs only 110 % of its new members) does not change that -- forced in place through the LDS budget instead
