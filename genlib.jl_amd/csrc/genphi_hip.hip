@@ -65,6 +65,10 @@ namespace {
 
 constexpr int kOrdMask = 0x7fffffff;
 
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
 // Float64 grouping of the reference recursion.
 //   a = Psi[A_i][A_j]  b = Psi[A_i][B_j]  c = Psi[B_i][A_j]  d = Psi[B_i][B_j]
 //   i climbs first (rank_i > rank_j): (a + b) + (c + d); otherwise (a + c) + (b + d).
@@ -219,11 +223,12 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         double *S = reinterpret_cast<double *>(lds);
         const float4 *a4 = reinterpret_cast<const float4 *>(r.rowA), *b4 = reinterpret_cast<const float4 *>(r.rowB);
         double2 *S2 = reinterpret_cast<double2 *>(S);
-        // the index words of a batch of columns are loaded one batch ahead -- the first batch here, in front of the row loads, so
-        // that it overlaps the staging: a workgroup is alive for ~10 us, and every L2 round trip it waits for alone is ~10 % of that
-        unsigned pkn[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) pkn[u] = p.pk[max(min(tid + u * nt, p.n - 1), 0)];      // (a rank's panel may have no column at all: n = 0)
+        // a thread takes QUADS of columns (16-byte index loads, 16-byte row stores); the index words of its next quad are loaded one
+        // iteration ahead -- the first one here, in front of the row loads, so that it overlaps the staging: a workgroup is alive for
+        // ~10 us, and every L2 round trip it waits for alone is ~10 % of that.  (pk is padded with "zero column" words: the last quad
+        // may run past n, the surplus entries are zeros inside the row's padding.)
+        const int nq = (p.n + 3) >> 2;
+        u4_t pkn = *reinterpret_cast<const u4_t *>(p.pk + 4 * max(min(tid, nq - 1), 0));      // (a rank's panel may have no column at all: n = 0)
         for (int base = tid; base < nvec; base += 2 * nt) {           // all loads of a batch in flight before the first LDS write
             const int k0 = base, k1 = min(base + nt, nvec - 1);
             const float4 x0 = a4[k0], x1 = a4[k1];
@@ -236,30 +241,23 @@ __global__ void __launch_bounds__(1024) level_full_kernel(const LevelArgs p)
         }
         const double sc = r.new_i ? 0.25 : 0.5;    // row weight times the column's 1/2 (a dragged column is A = B = itself)
         unsigned ckf = 0xffffffffu;
+        const int dq = (r.new_i && r.dcol >= 0) ? (r.dcol >> 2) : -1, de = r.dcol & 3;       // the quad / lane of the member's own entry
         __syncthreads();
-        for (int j0 = tid; j0 < p.n; j0 += U * nt) {
-            unsigned pk[U];
+        for (int q = tid; q < nq; q += nt) {
+            const u4_t pk4 = pkn;
+            if (q + nt < nq) pkn = *reinterpret_cast<const u4_t *>(p.pk + 4 * (q + nt));
+            f4_t v;
 #pragma unroll
-            for (int u = 0; u < U; ++u) pk[u] = pkn[u];
-            if (j0 + U * nt < p.n) {
+            for (int e = 0; e < 4; ++e) v[e] = static_cast<float>((S[pk4[e] & 0xffff] + S[pk4[e] >> 16]) * sc);
+            if (q == dq) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) pkn[u] = p.pk[min(j0 + U * nt + u * nt, p.n - 1)];
+                for (int e = 0; e < 4; ++e) v[e] = (e == de) ? r.diag : v[e];
             }
-            float v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = static_cast<float>((S[pk[u] & 0xffff] + S[pk[u] >> 16]) * sc);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + u * nt;
-                if (j < p.n) {
-                    const float val = (j == r.dcol && r.new_i) ? r.diag : v[u];
-                    ckf = min(ckf, cert_key(val));
-                    r.orowp[j] = val;
-                }
-            }
+            ckf = min(ckf, min(min(cert_key(v[0]), cert_key(v[1])), min(cert_key(v[2]), cert_key(v[3]))));
+            *reinterpret_cast<f4_t *>(r.orowp + 4 * q) = v;
         }
         if (p.cert_out && ckf < p.cert_thresh) p.cert_out[r.i] = 1;
-        for (long long j = p.n + tid; j < p.width; j += nt) r.orowp[j] = 0.f;
+        for (long long j = 4LL * nq + tid; j < p.width; j += nt) r.orowp[j] = 0.f;
         return;
     }
     stage_row<4>(sA, r.rowA, nvec, tid, nt);
@@ -332,9 +330,6 @@ __device__ __forceinline__ void st_off(void *sbase, unsigned byte_off, T v)
     *reinterpret_cast<T *>(static_cast<char *>(sbase) + byte_off) = v;
 }
 
-typedef float f4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-typedef int i4_t __attribute__((ext_vector_type(4)));
 
 // Row store of 4 consecutive columns.  AUX = 0: plain store; otherwise a buffer store with that
 // cache-policy word (16 = sc1: write-through, the line is not kept in the XCD's L2, so a
