@@ -295,7 +295,7 @@ def run_sparse(args):
                    "algorithmic_GB": best["algorithmic_bytes"] / 1e9, "call_wall_ms_mean": float(np.mean(t_wall)) * 1e3,
                    "call_wall_note": "whole gen.sparse_phi call: pruning, queue simulation, upload, sweep, download (host + device)",
                    "wave_ms": [round(float(x), 4) for x in wm] if len(wm) <= 64 else None},
-        "roofline": {"bound": "hbm", "kernel": "sparse_rows_kernel + sparse_compact_kernel + sparse_newnew_kernel + sparse_mirror_kernel",
+        "roofline": {"bound": "hbm", "kernel": "sparse_rows_compact_kernel + sparse_newnew_kernel + sparse_mirror_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "largest_wave": {"index": big, "GB": float(wb[big]) / 1e9, "ms": float(wm[big]),
                                       "frac": float(wb[big]) / (float(wm[big]) * 1e-3) / 1e9 / HBM_PEAK_GBS if wm[big] > 0 else None}},

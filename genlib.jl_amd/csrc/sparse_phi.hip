@@ -25,11 +25,12 @@
 // key, else 0 (src/compute.jl:366-390 looks up phi[min rank][max rank], :392-394 stores under
 // [rank of the live one][rank of the new one]).  The live set is a dense matrix in HBM ("active
 // matrix"), rebuilt after every wave as [survivors..., new...] (retired parents leave), like the cuts
-// of the dense path with other membership rules.  Per wave, all streaming, no host round trip:
-//   sparse_rows_kernel     the new rows against the old members: the two parent rows of the active matrix
+// of the dense path with other membership rules.  Per wave, all streaming, no host round trip (the first two passes are ONE launch,
+// sparse_rows_compact_kernel: both only read the old matrix):
+//   sparse_rows_body       the new rows against the old members: the two parent rows of the active matrix
 //                          streamed with 16-byte loads, masked by the key rule, written twice -- whole
 //                          (T, for the new x new block) and compacted into the next matrix (new x survivors)
-//   sparse_compact_kernel  survivors x survivors: a stream compaction of the old matrix
+//   sparse_compact_body    survivors x survivors: a stream compaction of the old matrix
 //   sparse_newnew_kernel   new x new, upper triangle in queue order: row j of T staged in LDS, two gathers
 //                          per entry; the self kinships
 //   sparse_mirror_kernel   survivors x new and the lower triangle by 64 x 64 tile transposition
@@ -101,13 +102,13 @@ __device__ __forceinline__ float rows_entry(int q, int n_old, int2 mq, float a, 
 // kRowsPerBlock new rows per workgroup share the index words of the thread's four slots (meta: 32 bytes, newpos: 16 bytes --
 // more than the 32 bytes of matrix data one row needs there).
 constexpr int kRowsPerBlock = 4;
-__global__ void __launch_bounds__(256)
-sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
-                   const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
-                   float *__restrict__ next, long long ld_next, int n_surv, int *__restrict__ so_cnt, int so_cap, int2 *__restrict__ so_rc,
-                   float *__restrict__ so_val)
+__device__ __forceinline__ void
+sparse_rows_body(int bx, int by, const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                 const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
+                 float *__restrict__ next, long long ld_next, int n_surv, int *__restrict__ so_cnt, int so_cap, int2 *__restrict__ so_rc,
+                 float *__restrict__ so_val)
 {
-    const int q0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int q0 = (by * 256 + threadIdx.x) * 4;
     if (q0 >= n_old) return;
     const int4 m01 = *reinterpret_cast<const int4 *>(meta + q0), m23 = *reinterpret_cast<const int4 *>(meta + q0 + 2);
     const int4 np4 = *reinterpret_cast<const int4 *>(newpos + q0);
@@ -116,7 +117,7 @@ sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__rest
     float4 a4s[kRowsPerBlock], b4s[kRowsPerBlock];
 #pragma unroll
     for (int rr = 0; rr < kRowsPerBlock; ++rr) {
-        const int i = min(blockIdx.x * kRowsPerBlock + rr, n_new - 1);
+        const int i = min(bx * kRowsPerBlock + rr, n_new - 1);
         pr[rr] = par[i];
         // (unconditional loads from a valid row: a select between a global pointer and a zero constant becomes a FLAT load of a
         // private copy; rows_entry drops the values of a missing parent)
@@ -125,7 +126,7 @@ sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__rest
     }
 #pragma unroll
     for (int rr = 0; rr < kRowsPerBlock; ++rr) {
-        const int i = blockIdx.x * kRowsPerBlock + rr;
+        const int i = bx * kRowsPerBlock + rr;
         if (i >= n_new) break;                                       // (workgroup-uniform)
         const int4 p = pr[rr];
         const float4 a4 = a4s[rr], b4 = b4s[rr];
@@ -154,14 +155,14 @@ sparse_rows_kernel(const float *__restrict__ M, long long ld, const int2 *__rest
 }
 
 // survivors x survivors: next[r][c] = M[keep[r]][keep[c]] (keep ascending: a stream compaction)
-__global__ void __launch_bounds__(256)
-sparse_compact_kernel(const float *__restrict__ M, long long ld, const int *__restrict__ keep, int n_surv, float *__restrict__ next,
-                      long long ld_next)
+__device__ __forceinline__ void
+sparse_compact_body(int bx, int by, const float *__restrict__ M, long long ld, const int *__restrict__ keep, int n_surv, float *__restrict__ next,
+                    long long ld_next)
 {
     constexpr int U = 8;
-    const float *src = M + (long long)keep[blockIdx.x] * ld;
-    float *dst = next + (long long)blockIdx.x * ld_next;
-    const int c0 = blockIdx.y * (256 * U) + threadIdx.x;
+    const float *src = M + (long long)keep[bx] * ld;
+    float *dst = next + (long long)bx * ld_next;
+    const int c0 = by * (256 * U) + threadIdx.x;
     int q[U];
     float v[U];
 #pragma unroll
@@ -172,6 +173,24 @@ sparse_compact_kernel(const float *__restrict__ M, long long ld, const int *__re
     for (int u = 0; u < U; ++u) {
         const int c = c0 + u * 256;
         if (c < n_surv) dst[c] = v[u];
+    }
+}
+
+// One launch per wave for the two passes that only READ the old active matrix (round 4; four launches per wave -> three): the first
+// rows_bx * rows_by workgroups compute the new rows (sparse_rows_body), the others compact survivors x survivors (sparse_compact_body).
+// Both stream independent parts of the next matrix; the short waves of a deep pedigree are bound by their launches.
+__global__ void __launch_bounds__(256)
+sparse_rows_compact_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                           const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ T, long long ldT,
+                           float *__restrict__ next, long long ld_next, int n_surv, int *__restrict__ so_cnt, int so_cap, int2 *__restrict__ so_rc,
+                           float *__restrict__ so_val, const int *__restrict__ keep, int rows_bx, int rows_by)
+{
+    const int b = blockIdx.x, rb = rows_bx * rows_by;
+    if (b < rb) {
+        sparse_rows_body(b % rows_bx, b / rows_bx, M, ld, meta, n_old, par, meta_new, n_new, newpos, T, ldT, next, ld_next, n_surv, so_cnt, so_cap, so_rc, so_val);
+    } else {
+        const int c = b - rb;
+        sparse_compact_body(c % n_surv, c / n_surv, M, ld, keep, n_surv, next, ld_next);
     }
 }
 
@@ -524,16 +543,17 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             const int4 *d_par = reinterpret_cast<const int4 *>(d_blob + w.o_par);
             const int *d_keep = reinterpret_cast<const int *>(d_blob + w.o_keep), *d_newpos = reinterpret_cast<const int *>(d_blob + w.o_newpos);
             const int2 *d_meta_new = reinterpret_cast<const int2 *>(d_blob + w.o_meta_new), *d_meta_old = reinterpret_cast<const int2 *>(d_blob + w.o_meta_old);
-            if (w.n_new > 0 && w.n_old > 0) {
-                dim3 grid(static_cast<unsigned>((w.n_new + kRowsPerBlock - 1) / kRowsPerBlock), static_cast<unsigned>((w.n_old + 1023) / 1024));
-                hipLaunchKernelGGL(sparse_rows_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new, w.n_new,
-                                   d_newpos, dT, ldT, dM[cur ^ 1], ld_next, w.n_surv, so.cnt, so.cap, so.rc, so.val);
-                SP_GO(hipGetLastError());
-            }
-            if (w.n_surv > 0) {
-                dim3 grid(static_cast<unsigned>(w.n_surv), static_cast<unsigned>((w.n_surv + 2047) / 2048));
-                hipLaunchKernelGGL(sparse_compact_kernel, grid, dim3(256), 0, st, dM[cur], ld_cur, d_keep, w.n_surv, dM[cur ^ 1], ld_next);
-                SP_GO(hipGetLastError());
+            {   // the new rows against the old members + survivors x survivors: ONE launch (both only read the old matrix)
+                const int rows_bx = (w.n_new > 0 && w.n_old > 0) ? (w.n_new + kRowsPerBlock - 1) / kRowsPerBlock : 0;
+                const int rows_by = rows_bx ? (w.n_old + 1023) / 1024 : 0;
+                const long long cb = w.n_surv > 0 ? static_cast<long long>(w.n_surv) * ((w.n_surv + 2047) / 2048) : 0;
+                const long long nb = static_cast<long long>(rows_bx) * rows_by + cb;
+                if (nb > 0) {
+                    hipLaunchKernelGGL(sparse_rows_compact_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, dM[cur], ld_cur, d_meta_old, w.n_old,
+                                       d_par, d_meta_new, w.n_new, d_newpos, dT, ldT, dM[cur ^ 1], ld_next, w.n_surv, so.cnt, so.cap, so.rc, so.val,
+                                       d_keep, rows_bx, rows_by);
+                    SP_GO(hipGetLastError());
+                }
             }
             if (w.n_new > 0) {
                 const int lds_floats = w.n_old <= 36864 ? (w.n_old + 3) / 4 * 4 : 0;

@@ -1,0 +1,3 @@
+cp genlib.jl_amd/lib/libgenphi.so /tmp/keep.so
+for rep in 1 2 3; do for v in build/libgenphi_sparse_head.so build/libgenphi_sparse_fused.so; do cp $v genlib.jl_amd/lib/libgenphi.so; for w in sparse140 sparse2k; do python bench.py --workload $w --steps 5 --warmup 1 2>/dev/null | python -c "import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v'.split('/')[-1], '$w', round(j['ms_per_step'], 4), round(j['roofline']['frac'], 3), round(j['config']['call_wall_ms_mean'], 2))"; done; done; done
+cp /tmp/keep.so genlib.jl_amd/lib/libgenphi.so
