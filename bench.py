@@ -41,6 +41,11 @@ WORKLOADS = {
     # path" (cuts to 20,540 members, up to 91 % of a cut dragged along, B = 26.25 GB, 1.66e9 pair evaluations).
     "cfg3s": (100_000, 10_000, 20, 50),
     "cfg2": "genea140",
+    # the same real genealogy with EVERY individual a proband (the full kinship matrix of a genealogy: 41,523 x 41,523): nobody ever
+    # leaves the cuts, B = 101 GB of which all but the new rows and columns is dragged x dragged copy (src/compute.jl:108-110)
+    "cfg2all": "genea140_all",
+    # ... and with a random quarter of its individuals (10,380 probands, ancestors among them at every depth)
+    "cfg2q": "genea140_quarter",
     "cfg5": "deep_inbred",
 }
 
@@ -77,6 +82,13 @@ def load_workload(name):
     if w == "genea140":
         ped = gen.genealogy(gen.genea140)
         return ped, gen.pro(ped), "genea140 bundled pedigree (41523 individuals, 140 probands)"
+    if w in ("genea140_all", "genea140_quarter"):
+        ped = gen.genealogy(gen.genea140)
+        ids = np.asarray(ped.ind, dtype=np.int64)
+        if w == "genea140_quarter":
+            ids = np.sort(np.random.default_rng(7).choice(ids, size=len(ids) // 4, replace=False))
+        return ped, ids, ("genea140 bundled pedigree (41523 individuals), " + ("every individual a proband" if w == "genea140_all" else
+                          f"a random quarter of the individuals as probands ({len(ids)}, numpy default_rng(7))"))
     if w == "deep_inbred":
         ind, fa, mo, sex, pro = synth.deep_inbred(200, 50, 3)
         desc = "deep consanguineous synthetic pedigree (1e4 individuals, 200 generations x 50, 3 sires/generation)"

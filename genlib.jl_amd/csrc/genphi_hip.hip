@@ -1913,6 +1913,8 @@ struct Tuning {
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
     int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour); 2 = in place wherever the ratio test allows, whatever the cost model says
     int stay_family = -1;          // GENPHI_STAY_FAMILY      A/B: 0 = new members of a leaving class in rank order instead of by family
+    int stay_last = -1;            // GENPHI_STAY_LAST        A/B + test: 0 = the proband cut never stays in place (the step that reads a run's last cut compacts it,
+                                   //                         then the proband-order pass: the form of rounds 3 and early 4)
     int stay_overhead_k = -1;      // GENPHI_STAY_OVERHEAD_K  tuning + test: fixed cost of a block-assembled step in the planner's cost model, in thousands of
                                    //                         matrix entries (default 64000; tests that put tiny cuts in place set 0)
     int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
@@ -1965,6 +1967,7 @@ static Tuning tuning_from_env()
     t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
     t.stay_narrow_min = geti("GENPHI_STAY_NARROW_MIN", -1);
     t.stay_overhead_k = geti("GENPHI_STAY_OVERHEAD_K", -1);
+    t.stay_last = geti("GENPHI_STAY_LAST", -1);
     t.stay_family = geti("GENPHI_STAY_FAMILY", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
@@ -2072,6 +2075,7 @@ struct genphi_plan {
     int *d_cert_p = nullptr;                     // certificates of the rows of psi_p
     size_t cert_p_words = 0;
     int *d_final_perm = nullptr;
+    int *d_final_slots = nullptr;                // (the proband cut stayed in place) slot of every proband, result order
     int *d_shard_rows = nullptr, *d_shard_out_rows = nullptr;
     int *d_queues = nullptr;        // 16 work-queue counters per slot (a level step or a new x new sub-step)
     size_t n_slots = 0;
@@ -2159,6 +2163,7 @@ static void free_device(genphi_plan *p)
     p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
     p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
     p->d_final_perm = nullptr;                       // lived inside idx_blob
+    p->d_final_slots = nullptr;
     p->dsteps.clear(); p->sh_steps.clear();
     p->sh_valid = false;
     p->shard_cap = 0; p->shard_r0 = p->shard_r1 = -1;
@@ -2200,6 +2205,7 @@ static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *fa
     if (p->tun.stay_narrow >= 0) { p->popt.stay_narrow = p->tun.stay_narrow != 0; p->popt.stay_narrow_force = p->tun.stay_narrow == 2; }
     if (p->tun.stay_narrow_min >= 0) p->popt.stay_narrow_min = p->tun.stay_narrow_min;
     if (p->tun.stay_overhead_k >= 0) p->popt.stay_step_overhead = 1000.0 * p->tun.stay_overhead_k;
+    if (p->tun.stay_last >= 0) p->popt.stay_last = p->tun.stay_last != 0;
     if (p->tun.stay_family >= 0) p->popt.stay_family_order = p->tun.stay_family != 0;
     if (p->tun.stay_headroom >= 0) p->popt.stay_headroom = p->tun.stay_headroom;
     if (p->tun.stay_mem_pct > 0) { p->popt.stay_mem_ratio = p->tun.stay_mem_pct / 100.0; p->popt.stay_mem_floor_bytes = 0.0; }   // (an explicit share is taken literally)
@@ -2372,7 +2378,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +
                      al(s.blk_slot.size() * sizeof(int)) + al((s.live_ranges.size() / 2 + static_cast<size_t>(s.stay ? s.P : 0) / 256 + 1) * sizeof(int2));
     }
-    total += al(pl.final_perm.size() * sizeof(int));
+    total += al(pl.final_perm.size() * sizeof(int)) + al(pl.final_slots.size() * sizeof(int));
     trace.mark("  upload: walk lists (host)");
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
     trace.mark("  upload: hipMalloc index blob");
@@ -2440,6 +2446,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         }
     }
     p->d_final_perm = reinterpret_cast<int *>(put(pl.final_perm.data(), pl.final_perm.size() * sizeof(int)));
+    p->d_final_slots = reinterpret_cast<int *>(put(pl.final_slots.data(), pl.final_slots.size() * sizeof(int)));
     trace.mark("  upload: host image");
     HIP_TRY(hipMemcpyAsync(p->idx_blob, host.data(), total, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));      // `host` goes out of scope
@@ -3271,7 +3278,11 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     // last step WIDE: the whole level (every row, [dragged, new] storage order) goes to final_tmp,
     // then rows [r0, r1) are delivered in proband order by colperm_kernel
     const bool need_perm = !pl.final_perm.empty();
-    if (need_perm) {
+    // ... unless the proband cut STAYED IN PLACE at the end of a run (Plan::final_slots): the last step then writes only the new probands'
+    // rows and columns into the run's matrix and colperm_kernel delivers from there, by slot -- one pass instead of a compaction + a
+    // permutation (genea140 with every individual a proband: the last step 7.7 -> ... ms).  The per-entry sweep (kernel = 1) knows no slots.
+    const bool last_by_slot = need_perm && !pl.final_slots.empty() && p->stay_active;
+    if (need_perm && !last_by_slot) {
         rc = ensure_floats(p, &p->final_tmp, &p->final_tmp_floats, static_cast<size_t>((N + 1) * ldN) + kTailPadFloats);
         if (rc) return rc;
     }
@@ -3473,8 +3484,9 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     if (kernel == 1 && st.mode != genphi::kModeWide)
                         HIP_TRY(hipMemsetAsync(out + st.n * st.ld, 0, static_cast<size_t>(st.ld) * sizeof(float), p->stream));
                 } else {
+                    float *lvl = last_by_slot ? p->buf[bid[s + 1]] : p->final_tmp;      // (in place: the run's own matrix)
                     if (need_perm)
-                        rc = launch_wide_level(p, s, psi, p->final_tmp, kernel);
+                        rc = launch_wide_level(p, s, psi, lvl, kernel);
                     else
                         rc = launch_level(p, main_ctx(p, s), psi, p->result, p->d_shard_rows, p->d_shard_out_rows,
                                           static_cast<int>(n_rows), kernel, p->shard_groups);
@@ -3483,16 +3495,17 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     if (need_perm) {
                         // columns per thread (registers: 2 per column) and LDS segments of the source row
                         const int per_thread = static_cast<int>((ldN + 1023) / 1024);
-                        const int n_chunks = (per_thread + 39) / 40;            // 40 columns per thread fit without spills
+                        const int n_chunks = (per_thread + 43) / 44;            // 44 columns per thread fit without spills (128 VGPRs; 48 spill):
+                                                                                // one chunk -- every source row staged once -- up to 45,056 columns
                         const int cpt = ((per_thread + n_chunks - 1) / n_chunks + 3) / 4 * 4;
                         const int seg_floats = 36864;
                         const int n_segs = static_cast<int>((ldN + seg_floats - 1) / seg_floats);
                         const size_t lds = static_cast<size_t>(std::min<int64_t>(seg_floats, ldN)) * sizeof(float);
                         const dim3 grid(static_cast<unsigned>(n_rows * n_chunks));
 #define GENPHI_CP(C) if (cpt <= C) { HIP_TRY(set_max_lds(reinterpret_cast<const void *>(colperm_kernel<C>), lds)); \
-                        hipLaunchKernelGGL(colperm_kernel<C>, grid, dim3(1024), lds, p->stream, p->final_tmp, p->result, ldN, \
-                                           static_cast<int>(N), p->d_final_perm, n_chunks, seg_floats, n_segs, static_cast<int>(r0)); } else
-                        GENPHI_CP(8) GENPHI_CP(16) GENPHI_CP(24) GENPHI_CP(32) GENPHI_CP(40)
+                        hipLaunchKernelGGL(colperm_kernel<C>, grid, dim3(1024), lds, p->stream, lvl, p->result, ldN, \
+                                           static_cast<int>(N), last_by_slot ? p->d_final_slots : p->d_final_perm, n_chunks, seg_floats, n_segs, static_cast<int>(r0)); } else
+                        GENPHI_CP(8) GENPHI_CP(16) GENPHI_CP(24) GENPHI_CP(32) GENPHI_CP(40) GENPHI_CP(44)
                         return fail(GENPHI_ERR_ARG, "internal: colperm geometry");
 #undef GENPHI_CP
                         HIP_TRY(hipGetLastError());

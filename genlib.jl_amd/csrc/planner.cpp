@@ -15,6 +15,7 @@
 #include "planner.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -433,9 +434,23 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         };
         // ... in place (only the new rows and columns move; the new x new block may go through the scatter buffer)
         auto cost_stay = [&](int32_t c) { return cost_nn(c) + nnew(c) * nnew(c) + 3.5 * nnew(c) * ndrag(c) + ov_blk; };
+        // The proband cut itself may stay in place at the end of a run: its step then writes only the new probands' rows and columns
+        // and the result is DELIVERED from the slot matrix by one permutation pass (colperm_kernel with the probands' slots) instead of
+        // being compacted into storage order first and permuted then.  deliver = that pass (every proband's row of the slot matrix staged
+        // once per chunk of 40k result columns, N^2 entries written), charged to the run that ends in the proband cut.
+        const double n_last = static_cast<double>(size_of[L - 1]);
+        const double deliver = n_last * 1.1 * static_cast<double>(*std::max_element(size_of.begin(), size_of.end())) * std::ceil(n_last / 40960.0) + n_last * n_last;
+        if (opt.stay_last && L >= 3) {
+            const int32_t c = L - 1;
+            const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min &&
+                                (opt.stay_narrow_force || cost_stay(c) + deliver < (blk[c] ? cost_blk(c) + deliver : cost_rows(c)));
+            want[c] = (blk[c] || narrow) && 100 * size_of[c] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
+                      size_of[c] > static_cast<int64_t>(new_of[c].size()) && nn_ok(c);
+        }
         for (int32_t c = 2; c + 1 < L; ++c) {
             const bool by_width = blk[c] && blk[c + 1];                  // both steps assemble blocks anyway
-            const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min && c + 2 < L &&      // (the reader is never the proband step)
+            const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min &&
+                                (c + 2 < L || want[L - 1]) &&            // (the proband step reads a cut stored by slot only when it stays in place itself)
                                 (opt.stay_narrow_force || cost_stay(c) < (blk[c] ? cost_blk(c) : cost_rows(c)));
             want[c] = (by_width || narrow) && 100 * size_of[c] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
                       size_of[c] > static_cast<int64_t>(new_of[c].size()) && nn_ok(c) && nn_ok(c + 1);
@@ -443,11 +458,18 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         for (int32_t c = 2; c + 1 < L;) {
             if (!want[c]) { ++c; continue; }
             int32_t e = c;
-            while (e + 2 < L && want[e + 1]) ++e;
-            // the step that reads the run's last cut by slot assembles blocks: a loss when it would have been a row-kernel level
-            double gain = blk[e + 1] ? 0.0 : cost_rows(e + 1) - cost_blk(e + 1);
+            while (e + 1 < L && want[e + 1]) ++e;                        // (may reach the proband cut L - 1)
+            double gain;
+            bool all_wide;
+            if (e == L - 1) {                                            // no step reads this run's last cut: the delivery pass instead
+                gain = (blk[e] ? deliver : 0.0) - deliver;
+                all_wide = true;
+            } else {
+                // the step that reads the run's last cut by slot assembles blocks: a loss when it would have been a row-kernel level
+                gain = blk[e + 1] ? 0.0 : cost_rows(e + 1) - cost_blk(e + 1);
+                all_wide = blk[e + 1] != 0;
+            }
             for (int32_t cc = c; cc <= e; ++cc) gain += (blk[cc] ? cost_blk(cc) : cost_rows(cc)) - cost_stay(cc);
-            bool all_wide = blk[e + 1] != 0;
             for (int32_t cc = c; cc <= e; ++cc) all_wide = all_wide && blk[cc];
             if (all_wide || gain > 0.0 || opt.stay_narrow_force) run_end[c] = e;
             c = e + 1;
@@ -580,9 +602,14 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
                 done = cc;
             }
             if (done >= c) {
+                // (a proband cut that stays in place: the RESULT takes the run's pitch too -- plan.ld[L - 1] is the result's row pitch)
                 for (int32_t cc = c - 1; cc <= done; ++cc) { slotP[cc] = static_cast<int32_t>(P); plan.ld[cc] = P; }
-                for (int32_t cc = c; cc <= done + 1; ++cc) blk[cc] = 1;      // the run's steps and the step that leaves it assemble blocks
-                sources(done + 1);                                   // the step that leaves the run reads by slot
+                for (int32_t cc = c; cc <= std::min(done + 1, L - 1); ++cc) blk[cc] = 1;      // the run's steps and the step that leaves it assemble blocks
+                if (done + 1 < L) sources(done + 1);                 // the step that leaves the run reads by slot
+                else {                                               // the run ends in the proband cut: delivered from the probands' slots
+                    plan.final_slots.resize(plan.final_members.size());
+                    for (size_t k = 0; k < plan.final_members.size(); ++k) plan.final_slots[k] = slot_of[plan.final_members[k]];
+                }
                 // (a run the slot space ended early: what is left of it may start again behind the compacting step)
                 if (done + 2 <= e && done + 2 + 1 < L) run_end[done + 2] = e;
                 c = done + 2;

@@ -95,6 +95,10 @@ struct Plan {
     // The final cut is kept in [dragged, new] order when its step is WIDE; perm maps result
     // (proband) position -> storage position.  Empty = storage order is proband order.
     std::vector<int32_t> final_perm;
+    // The last cut stayed in place (LevelStep::stay of the last step): slot of every proband, result order, in the run's matrix.  The
+    // result is then delivered by ONE permutation pass from that matrix (its pitch -- ld[L-1] -- is the run's); final_perm keeps the
+    // compact [dragged, new] meaning for the sweeps that know no slots.
+    std::vector<int32_t> final_slots;
     double algorithmic_bytes = 0.0;          // 4 * sum (n_k^2 + n_{k+1}^2)
     int64_t max_cut = 0;
 };
@@ -115,6 +119,7 @@ struct PlanOptions {
                                       // assembly when the cost model says the dragged x dragged copy that is saved outweighs the extra passes
     double stay_step_overhead = 64e6;  // fixed cost of a block-assembled step in the cost model, in matrix entries (its six to eight short launches; a row-kernel
                                       // level is charged 15 % of it); tests that put tiny cuts in place set it to 0
+    bool stay_last = true;            // the proband cut may stay in place at the end of a run (the result is delivered from the slot matrix)
     bool stay_narrow_force = false;   // A/B hook: ... whatever the cost model says (every step that passes the ratio test)
     int64_t stay_narrow_min = 2048;   // ... from this width of the source cut on (narrower levels are bound by their launches, not their bytes)
     bool stay_family_order = true;    // new members of a cut of an in-place plan: siblings (same father) adjacent inside a leaving class

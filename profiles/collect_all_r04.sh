@@ -15,8 +15,11 @@ for w in cfg4 cfg3s cfg3 cfg2 cfg5 cfg4o; do
   echo "collected $w"
 done
 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_cfg4.json" 2> "$O/bench_cfg4.err"; echo "bench cfg4"
-for w in cfg3s cfg2 cfg3 cfg5; do python bench.py --workload $w --steps 20 --warmup 3 > "$O/${TAG}_bench_$w.json" 2> "$O/bench_$w.err"; echo "bench $w"; done
+for w in cfg3s cfg2 cfg3 cfg5 cfg2all cfg2q; do python bench.py --workload $w --steps 20 --warmup 3 > "$O/${TAG}_bench_$w.json" 2> "$O/bench_$w.err"; echo "bench $w"; done
 GENPHI_STAY_NARROW=0 python bench.py --workload cfg3s --steps 20 --warmup 3 --no-cpu-baseline > "$O/${TAG}_bench_cfg3s_nothing_in_place.json" 2>/dev/null
+GENPHI_STAY_NARROW=0 python bench.py --workload cfg2all --steps 10 --warmup 2 --no-cpu-baseline --no-d2h > "$O/${TAG}_bench_cfg2all_round3_plan.json" 2>/dev/null
+GENPHI_NO_STAY=1 python bench.py --workload cfg2all --steps 10 --warmup 2 --no-cpu-baseline --no-d2h > "$O/${TAG}_bench_cfg2all_nothing_in_place.json" 2>/dev/null
+GENPHI_STAY_LAST=0 python bench.py --workload cfg2all --steps 10 --warmup 2 --no-cpu-baseline --no-d2h > "$O/${TAG}_bench_cfg2all_proband_cut_compacted.json" 2>/dev/null
 python bench.py --workload cfg4o --steps 5 --warmup 1 --no-cpu-baseline > "$O/${TAG}_bench_cfg4o.json" 2> "$O/bench_cfg4o.err"; echo "bench cfg4o"
 for w in cfg3 cfg2; do python bench.py --workload $w --storage f64 --steps 10 --warmup 2 > "$O/${TAG}_bench_${w}_f64.json" 2> "$O/bench_${w}_f64.err"; done
 for w in sparse140 sparse2k; do python bench.py --workload $w --steps 5 --warmup 1 > "$O/${TAG}_bench_$w.json" 2> "$O/bench_$w.err"; done

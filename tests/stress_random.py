@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K"]
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST"]
 
 
 def make_case(case):
@@ -33,6 +33,8 @@ def make_case(case):
     if r.random() < 0.4:                                                  # probands: a subset, some ancestors, duplicates
         extra = ind[r.integers(0, len(ind), size=int(r.integers(1, 20)))]
         pro = np.concatenate([r.permutation(pro)[: max(2, n_pro // 2)], extra, pro[:2]])
+    # (round 4) probands at every depth: a random share of ALL individuals, or every one of them -- nobody then leaves the cuts, runs of
+    # in-place steps reach the proband cut and the result is delivered from the slot matrix
     env = {}
     if r.random() < 0.7:
         env["GENPHI_LDS_CAP_FLOATS"] = str(int(r.choice([64, 256, 700, 1500, 4096])))
@@ -72,6 +74,10 @@ def make_case(case):
         env["GENPHI_STAY_NARROW"] = "0"
     if r.random() < 0.3:
         env["GENPHI_STAY_MIN_RATIO_PCT"] = str(int(r.choice([110, 150, 300])))       # in place with few dragged members too / only with many
+    if r.random() < 0.2:
+        pro = ind.copy() if r.random() < 0.5 else r.permutation(ind)[: max(3, len(ind) // int(r.integers(2, 6)))]
+    if r.random() < 0.2:
+        env["GENPHI_STAY_LAST"] = "0"                                             # the proband cut never stays in place
     if r.random() < 0.25:
         env["GENPHI_STAY_SCALAR_T"] = "1"                                         # the fused in-place kernel's transposed tile by 4-byte stores
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env

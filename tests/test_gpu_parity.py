@@ -354,6 +354,44 @@ def test_wide_in_place_at_real_size_default_settings(gen, oracle):
     pl.close()
 
 
+def test_real_genealogy_every_individual_a_proband(gen, oracle, monkeypatch):
+    """The full kinship matrix of a genealogy: genea140 with EVERY one of its 41,523 individuals a proband (nobody ever leaves the
+    cuts: B = 101 GB, nearly all of it dragged x dragged copy, src/compute.jl:108-110).  Default settings: eleven steps in place,
+    the proband cut included -- its step writes the last 140 rows and columns and the result is DELIVERED from the slot matrix by one
+    permutation pass (Plan::final_slots).  Bit for bit against the oracle (6.7e9 pair evaluations, ~50 s), the whole 41,523 x 41,523
+    matrix; a row shard; and a random quarter of the individuals (10,380 probands, ancestors among them at every depth) with the
+    proband cut in place or not (GENPHI_STAY_LAST=0) and with nothing in place."""
+    ped = gen.genealogy(gen.genea140)
+    oped = oracle.Pedigree.from_file(gen.genea140)
+    ids = np.asarray(ped.ind, dtype=np.int64)
+    pl = gen.plan(ped, ids)
+    sizes, both = pl.levels()
+    flags = [pl.step_slots(k) for k in range(len(sizes) - 1)]
+    assert pl.n_probands == 41_523 and sum(f[0] & 1 for f in flags) >= 10 and flags[-1][0] & 1      # the last step stays in place too
+    want = oped.phi(ids)
+    got = pl.compute()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    _assert_equal(pl.compute(rows=(20_000, 20_300)), want[20_000:20_300])
+    _assert_equal(pl.compute(rows=(41_000, 41_523)), want[41_000:])
+    pl.close()
+    del got
+    sub = np.sort(np.random.default_rng(7).choice(ids, size=len(ids) // 4, replace=False))
+    wsub = oped.phi(sub)
+    for env in ({}, {"GENPHI_STAY_LAST": "0"}, {"GENPHI_STAY_NARROW": "2"}, {"GENPHI_STAY_NARROW": "2", "GENPHI_CERT_MIN_EXP": "-6"}, {"GENPHI_NO_STAY": "1"}):
+        for k in ("GENPHI_STAY_LAST", "GENPHI_STAY_NARROW", "GENPHI_NO_STAY", "GENPHI_CERT_MIN_EXP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, sub)
+        for rep in range(3):
+            _assert_equal(pl.compute(), wsub)
+        _assert_equal(pl.compute(kernel=1), wsub)
+        _assert_equal(pl.compute(rows=(5_000, 5_700)), wsub[5_000:5_700])
+        pl.close()
+    for k in ("GENPHI_STAY_LAST", "GENPHI_STAY_NARROW", "GENPHI_NO_STAY", "GENPHI_CERT_MIN_EXP"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_many_probands_from_few_parents(gen, oracle, monkeypatch):
     """A final level much wider than the cut above it (1100 parents, 20 000 probands: 18 children per
     parent): the FULL kernel walks 20 000 columns per row from two 4.4 KB source rows; the same pedigree
