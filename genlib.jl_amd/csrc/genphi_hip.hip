@@ -1860,6 +1860,75 @@ colperm_kernel(const float *__restrict__ in, float *__restrict__ out, long long 
     }
 }
 
+
+// The same delivery, persistent and software-pipelined (round 4; rows of up to 45,056 result columns from source rows of < 65,535 floats):
+// the column permutation is the SAME for every row, so a workgroup loads it once -- packed two 16-bit source columns per register --
+// (512 threads x 88 columns: 44 + 88 + 72 staging registers of the 256 a thread has at two waves per SIMD; with 1024 threads the 128 do not hold
+// them) and then walks rows blockIdx.x, + gridDim.x, ...: ONE flat loop over (row, segment) stages in which the next stage's piece of a source
+// row is already in flight into registers while the current one is gathered from LDS and the finished row is stored (colperm_kernel has
+// one workgroup per row and CU -- LDS -- and nothing overlaps its loads: 3.8 TB/s on the 41.5k x 41.5k result of cfg2all).
+template <int NT, int CPT, int STG>
+__global__ void __launch_bounds__(NT)
+colperm_pipe_kernel(const float *__restrict__ in, float *__restrict__ out, long long ld, int n, const int *__restrict__ perm,
+                    int seg_floats, int n_segs, int row_begin, int n_rows)
+{
+    extern __shared__ float lds[];
+    static_assert(CPT % 4 == 0, "columns are handled in quads");
+    constexpr int NQ = CPT / 4;
+    const int tid = threadIdx.x;
+    unsigned pp[CPT / 2];                                           // source column of result column k: 16 bits each, 0xffff = padding (stays 0)
+    float val[CPT];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const long long j = ((long long)q * NT + tid) * 4;
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w[e] = (j + e < n) ? static_cast<unsigned>(perm[j + e]) : 0xffffu; val[4 * q + e] = 0.f; }
+        pp[2 * q] = w[0] | (w[1] << 16); pp[2 * q + 1] = w[2] | (w[3] << 16);
+    }
+    int row = blockIdx.x;
+    if (row >= n_rows) return;
+    f4_t pre[STG];
+    auto fetch = [&](int r, int sg) {                              // the piece [sg * seg_floats, ...) of result row r's source row
+        const float *src = in + (long long)perm[row_begin + r] * ld + (long long)sg * seg_floats;
+        const int nvec = (min(seg_floats, (int)ld - sg * seg_floats)) >> 2;
+#pragma unroll
+        for (int k = 0; k < STG; ++k) pre[k] = *reinterpret_cast<const f4_t *>(src + 4 * min(tid + k * NT, nvec - 1));      // (clamped: unconditional loads)
+    };
+    fetch(row, 0);
+    int sg = 0;
+    for (;;) {
+        const int base = sg * seg_floats;
+        const int len = min(seg_floats, (int)ld - base);           // ld is a multiple of 64
+        __syncthreads();                                            // the previous stage's gathers are done with the buffer
+#pragma unroll
+        for (int k = 0; k < STG; ++k) { const int q4 = tid + k * NT; if (4 * q4 < len) *reinterpret_cast<f4_t *>(lds + 4 * q4) = pre[k]; }
+        // the next stage: the next piece of this row, or the first piece of the workgroup's next row
+        const bool row_done = sg + 1 == n_segs;
+        const int nrow = row_done ? row + (int)gridDim.x : row, nsg = row_done ? 0 : sg + 1;
+        if (nrow < n_rows) fetch(nrow, nsg);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            unsigned w = pp[k >> 1];
+            asm volatile("" : "+v"(w));                             // (opaque: the unpacked halves are loop-invariant and would be hoisted into 88 registers)
+            const unsigned t = ((w >> ((k & 1) * 16)) & 0xffffu) - (unsigned)base;
+            if (t < (unsigned)len) val[k] = lds[t];
+        }
+        if (row_done) {
+            float *dst = out + (long long)row * ld;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const long long j = ((long long)q * NT + tid) * 4;
+                if (j < ld) __builtin_nontemporal_store(f4_t{val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]}, reinterpret_cast<f4_t *>(dst + j));
+                val[4 * q] = val[4 * q + 1] = val[4 * q + 2] = val[4 * q + 3] = 0.f;
+            }
+            if (nrow >= n_rows) break;
+        }
+        row = nrow; sg = nsg;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1913,6 +1982,7 @@ struct Tuning {
     int stay_slack_pct = -1;       // GENPHI_STAY_SLACK_PCT   tuning: free slots beyond the widest (cut + new members) of an in-place run, in % (default 6)
     int stay_narrow = -1;          // GENPHI_STAY_NARROW      A/B + test: 0 = only levels whose rows do not fit in LDS stay in place (the round-3 behaviour); 2 = in place wherever the ratio test allows, whatever the cost model says
     int stay_family = -1;          // GENPHI_STAY_FAMILY      A/B: 0 = new members of a leaving class in rank order instead of by family
+    bool colperm_plain = false;    // GENPHI_COLPERM_PLAIN    A/B + test: the proband-order pass by the one-workgroup-per-row kernel (rounds 1-3)
     int stay_last = -1;            // GENPHI_STAY_LAST        A/B + test: 0 = the proband cut never stays in place (the step that reads a run's last cut compacts it,
                                    //                         then the proband-order pass: the form of rounds 3 and early 4)
     int stay_overhead_k = -1;      // GENPHI_STAY_OVERHEAD_K  tuning + test: fixed cost of a block-assembled step in the planner's cost model, in thousands of
@@ -1968,6 +2038,7 @@ static Tuning tuning_from_env()
     t.stay_narrow_min = geti("GENPHI_STAY_NARROW_MIN", -1);
     t.stay_overhead_k = geti("GENPHI_STAY_OVERHEAD_K", -1);
     t.stay_last = geti("GENPHI_STAY_LAST", -1);
+    t.colperm_plain = has("GENPHI_COLPERM_PLAIN");
     t.stay_family = geti("GENPHI_STAY_FAMILY", -1);
     t.max_group = std::max(1, geti("GENPHI_MAX_GROUP", 8));
     t.max_run = std::max(1, geti("GENPHI_MAX_RUN", 1));
@@ -3502,6 +3573,16 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                         const int n_segs = static_cast<int>((ldN + seg_floats - 1) / seg_floats);
                         const size_t lds = static_cast<size_t>(std::min<int64_t>(seg_floats, ldN)) * sizeof(float);
                         const dim3 grid(static_cast<unsigned>(n_rows * n_chunks));
+                        if (n_chunks == 1 && ldN < 65535 && !p->tun.colperm_plain) {
+                            // one chunk, 16-bit source columns: the persistent pipelined form
+                            const int seg_p = 32768;                      // 16 float4 per thread and piece (18 -- 36,864 floats -- spill)
+                            const int n_segs_p = static_cast<int>((ldN + seg_p - 1) / seg_p);
+                            const size_t lds_p = static_cast<size_t>(std::min<int64_t>(seg_p, ldN)) * sizeof(float);
+                            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(colperm_pipe_kernel<512, 88, 16>), lds_p));
+                            hipLaunchKernelGGL((colperm_pipe_kernel<512, 88, 16>), dim3(static_cast<unsigned>(std::min<int64_t>(n_rows, p->n_cus))), dim3(512), lds_p, p->stream,
+                                               lvl, p->result, ldN, static_cast<int>(N), last_by_slot ? p->d_final_slots : p->d_final_perm, seg_p, n_segs_p,
+                                               static_cast<int>(r0), static_cast<int>(n_rows));
+                        } else
 #define GENPHI_CP(C) if (cpt <= C) { HIP_TRY(set_max_lds(reinterpret_cast<const void *>(colperm_kernel<C>), lds)); \
                         hipLaunchKernelGGL(colperm_kernel<C>, grid, dim3(1024), lds, p->stream, lvl, p->result, ldN, \
                                            static_cast<int>(N), last_by_slot ? p->d_final_slots : p->d_final_perm, n_chunks, seg_floats, n_segs, static_cast<int>(r0)); } else
