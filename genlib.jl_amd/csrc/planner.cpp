@@ -442,8 +442,14 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         const double deliver = n_last * 1.1 * static_cast<double>(*std::max_element(size_of.begin(), size_of.end())) * std::ceil(n_last / 40960.0) + n_last * n_last;
         if (opt.stay_last && L >= 3) {
             const int32_t c = L - 1;
+            // (when the cut before the probands could stay in place as well, stopping short of the probands also costs the compacting
+            // step that then has to produce that cut: the alternative to "through the proband cut" is dearer by that much)
+            double stop_short = 0.0;
+            if (c >= 3 && opt.stay_narrow && size_of[c - 2] >= opt.stay_narrow_min && size_of[c - 1] > static_cast<int64_t>(new_of[c - 1].size()) &&
+                100 * size_of[c - 1] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c - 1].size()) && nn_ok(c - 1))
+                stop_short = std::max(0.0, cost_blk(c - 1) - cost_stay(c - 1));
             const bool narrow = opt.stay_narrow && size_of[c - 1] >= opt.stay_narrow_min &&
-                                (opt.stay_narrow_force || cost_stay(c) + deliver < (blk[c] ? cost_blk(c) + deliver : cost_rows(c)));
+                                (opt.stay_narrow_force || cost_stay(c) + deliver < (blk[c] ? cost_blk(c) + deliver : cost_rows(c) + stop_short));
             want[c] = (blk[c] || narrow) && 100 * size_of[c] >= static_cast<int64_t>(opt.stay_min_ratio_pct) * static_cast<int64_t>(new_of[c].size()) &&
                       size_of[c] > static_cast<int64_t>(new_of[c].size()) && nn_ok(c);
         }
