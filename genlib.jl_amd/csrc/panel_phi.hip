@@ -565,7 +565,8 @@ int genphi_panel_begin(genphi_panel *p, int32_t device)
     }
     PN_TRY(hipMemsetAsync(p->d_cert[0], 0, (static_cast<size_t>(pl.max_cut) + 1) * sizeof(int), p->stream));   // 1/2 I: every row certified
     p->cur = 0;
-    PN_TRY(hipStreamSynchronize(p->stream));
+    // (no synchronisation: everything that follows is ordered behind this on the panel's stream -- the blocking pack / compute calls
+    // synchronise themselves, the stream-ordered ones end in genphi_panel_sync)
     return GENPHI_OK;
 }
 
