@@ -1272,20 +1272,23 @@ transpose_slots_kernel(float *m, long long ld, int n_new, const int *__restrict_
 // (m[c][slot(r)], 256-byte runs) -- the new rows are not read back.  rowdesc: the step's new rows in granule order
 // (A, B, output row = slot, scale).  Source and destination are the same matrix: the tile's rows and the new columns hold no
 // member of the source cut.  Certificates of both the new rows and the rows c.
-constexpr int kFT = 256;
+// (tile widths: the template parameter FT of rows_avg_t_kernel)
 // rows of a wave's share whose parent-row loads are in flight together (2 x 16-byte loads per row and lane).  With the tile in LDS the
 // kernel runs two waves per SIMD, so the bytes in flight have to come from each wave: same-box A/B, cfg3s 3.56 / 3.40 / 3.42 ms and
 // cfg4o 155.4 / 148.8 / 147.9 ms at 4 / 8 / 16 rows (profiles/microbench/out/r04_ab_rows_avg_t_rows_in_flight_*.out)
 #ifndef GENPHI_AVG_T_ROWS
 #define GENPHI_AVG_T_ROWS 16
 #endif
-// (LDS holds the kernel to two workgroups = two waves per SIMD anyway: let the compiler use the registers of that occupancy)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+// FT = columns of a tile: 256 (a wave-instruction covers one row piece of 1 KB; the 66 KB tile holds the kernel to two workgroups per CU) or
+// 128 (two row pieces of 512 bytes per wave-instruction; 33 KB: four workgroups per CU).
+template <int FT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
 rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ rowdesc, int n_new, const int *__restrict__ blk_slot,
                   const int2 *__restrict__ tiles, int *__restrict__ cert_out, unsigned cert_thresh, int gran_fastest, int scalar_t)
 {
-    extern __shared__ float tile_dyn[];                          // [64][kFT + 1]
-    float (*tile)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(tile_dyn);
+    extern __shared__ float tile_dyn[];                          // [64][FT + 1]
+    float (*tile)[FT + 1] = reinterpret_cast<float (*)[FT + 1]>(tile_dyn);
+    constexpr int LPR = FT / 4, RPI = 64 / LPR;                  // lanes per row piece, rows per wave-instruction
     // (gran_fastest: consecutive workgroups take the SAME columns of different granules -- a parent's row piece is then read by
     // its children's workgroups close in time)
     const int g = gran_fastest ? blockIdx.x : blockIdx.y, ct = gran_fastest ? blockIdx.y : blockIdx.x;
@@ -1294,31 +1297,32 @@ rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ row
     const int c0 = tl.x, c_hi = tl.y, c_lo = tl.x;
     const int base = blk_slot[g], rows_here = min(64, n_new - g * 64);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = c0 + lane * 4;                                // this lane's four columns (ranges are multiples of 64 columns)
+    const int lc = (lane % LPR) * 4, lr = lane / LPR;            // this lane's four columns of the tile, its row inside a wave-instruction
+    const int c = c0 + lc;                                       // (ranges are multiples of 64 columns)
     const bool in = c < c_hi;
-    // ---- new x dragged: 16 rows per wave, RB at a time (2 RB 16-byte loads in flight per lane) ----
-    constexpr int RB = GENPHI_AVG_T_ROWS;
-    for (int r0 = w * 16; r0 < w * 16 + 16; r0 += RB) {
+    // ---- new x dragged: 16 rows per wave, RB at a time (2 RB / RPI 16-byte loads in flight per lane) ----
+    constexpr int RB = GENPHI_AVG_T_ROWS / RPI;                  // wave-instructions per batch
+    for (int r0 = w * 16; r0 < w * 16 + 16; r0 += RB * RPI) {
         int4 d[RB];
         f4_t a[RB], b[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            d[u] = rowdesc[g * 64 + min(r0 + u, rows_here - 1)];
+            d[u] = rowdesc[g * 64 + min(r0 + u * RPI + lr, rows_here - 1)];
             const int cc = in ? c : c_lo;                        // (clamped: unconditional loads)
             a[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].x * ld + cc);
             b[u] = *reinterpret_cast<const f4_t *>(m + (long long)d[u].y * ld + cc);       // ("none" is the all-zero row)
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const int r = r0 + u;
-            if (r >= rows_here) continue;                        // (wave-uniform; `continue`, not `break`: the loop must unroll, d / a / b are registers)
+            const int r = r0 + u * RPI + lr;
+            if (r >= rows_here) continue;                        // (`continue`, not `break`: the loop must unroll, d / a / b are registers)
             const double sc = d[u].w == 0 ? 1.0 : 0.5;
             f4_t v;
             unsigned ck = 0xffffffffu;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = static_cast<float>((static_cast<double>(a[u][e]) + static_cast<double>(b[u][e])) * sc);
-                tile[r][lane * 4 + e] = v[e];
+                tile[r][lc + e] = v[e];
                 ck = min(ck, cert_key(v[e]));
             }
             if (in) {
@@ -1333,7 +1337,7 @@ rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ row
         // 16-byte stores: a lane takes four consecutive new members (tile rows 4 q .. 4 q + 3) of one destination row, sixteen lanes
         // cover the row's 256-byte run, a wave four destination rows per instruction
         const int q = lane & 15, sub = lane >> 4;
-        for (int k = w * 4 + sub; k < kFT; k += 16) {
+        for (int k = w * 4 + sub; k < FT; k += 16) {
             const int cr = c0 + k;
             if (cr < c_hi) {
                 f4_t v;
@@ -1345,7 +1349,7 @@ rows_avg_t_kernel(float *m, long long ld, int none, const int4 *__restrict__ row
         }
     } else {
         const int tx = lane;
-        for (int k = w; k < kFT; k += 4) {
+        for (int k = w; k < FT; k += 4) {
             const int cr = c0 + k;
             if (cr < c_hi && tx < rows_here) {
                 const float v = tile[tx][k];
@@ -1988,6 +1992,7 @@ struct Tuning {
     int stay_overhead_k = -1;      // GENPHI_STAY_OVERHEAD_K  tuning + test: fixed cost of a block-assembled step in the planner's cost model, in thousands of
                                    //                         matrix entries (default 64000; tests that put tiny cuts in place set 0)
     int stay_narrow_min = -1;      // GENPHI_STAY_NARROW_MIN  tuning + test: narrowest source cut of an in-place step at FULL / SPLIT widths (default 2048)
+    int stay_tile = 0;             // GENPHI_STAY_TILE        tuning: columns per tile of the fused in-place kernel, 256 or 128 (default: by the launch's size)
     bool stay_scalar_t = false;    // GENPHI_STAY_SCALAR_T    A/B: the fused kernel writes its transposed tile with 4-byte stores (the round-3 form) instead of 16-byte ones
     bool stay_col_fastest = false; // GENPHI_STAY_COL_FASTEST A/B: fused kernel's workgroups ordered column-fastest instead of granule-fastest (same columns together)
     bool stay_two_pass = false;    // GENPHI_STAY_TWO_PASS    A/B + test: new x dragged and its transpose as two kernels (rows_avg + transpose_slots) instead of the fused one
@@ -2032,6 +2037,7 @@ static Tuning tuning_from_env()
     t.stay_two_pass = geti("GENPHI_STAY_TWO_PASS", 0) != 0;
     t.stay_col_fastest = geti("GENPHI_STAY_COL_FASTEST", 0) != 0;
     t.stay_scalar_t = geti("GENPHI_STAY_SCALAR_T", 0) != 0;
+    { const int v = geti("GENPHI_STAY_TILE", 0); t.stay_tile = v == 128 ? 128 : (v == 256 ? 256 : 0); }
     t.stay_slack_pct = geti("GENPHI_STAY_SLACK_PCT", -1);
     t.stay_min_ratio_pct = geti("GENPHI_STAY_MIN_RATIO_PCT", -1);
     t.stay_narrow = geti("GENPHI_STAY_NARROW", -1);
@@ -2099,6 +2105,7 @@ struct DeviceStep {
     int *blk_slot = nullptr;   // (in-place steps) first slot of every granule of 64 new members
     int2 *tiles = nullptr;     // (in-place steps) the kFT-column tiles of the slot ranges that hold dragged members: (first column, end of the range)
     int n_tiles = 0;
+    int tile_cols = 256;       // ... their width: 128 for small launches (more, smaller workgroups: cfg3s -2.4 %), 256 otherwise (GENPHI_STAY_TILE forces one)
     int nn = -1;               // index of the new x new sub-step in genphi_plan::nn_steps / nn_dsteps
 };
 
@@ -2447,7 +2454,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +
-                     al(s.blk_slot.size() * sizeof(int)) + al((s.live_ranges.size() / 2 + static_cast<size_t>(s.stay ? s.P : 0) / 256 + 1) * sizeof(int2));
+                     al(s.blk_slot.size() * sizeof(int)) + al((s.live_ranges.size() / 2 + static_cast<size_t>(s.stay ? s.P : 0) / 128 + 1) * sizeof(int2));
     }
     total += al(pl.final_perm.size() * sizeof(int)) + al(pl.final_slots.size() * sizeof(int));
     trace.mark("  upload: walk lists (host)");
@@ -2498,8 +2505,11 @@ static int upload_plan_impl(genphi_plan *p, int device)
             d.blk_slot = reinterpret_cast<int *>(put(s.blk_slot.data(), s.blk_slot.size() * sizeof(int)));
             {   // column tiles of rows_avg_t_kernel over all live ranges (one launch per step)
                 std::vector<int2> tl;
+                long long cols_live = 0;
+                for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2) cols_live += s.live_ranges[h + 1] - s.live_ranges[h];
+                d.tile_cols = p->tun.stay_tile ? p->tun.stay_tile : ((cols_live / 256 + 1) * static_cast<long long>(s.blk_slot.size()) < 8192 ? 128 : 256);
                 for (size_t h = 0; h + 1 < s.live_ranges.size(); h += 2)
-                    for (int c0 = s.live_ranges[h]; c0 < s.live_ranges[h + 1]; c0 += kFT) tl.push_back(make_int2(c0, s.live_ranges[h + 1]));
+                    for (int c0 = s.live_ranges[h]; c0 < s.live_ranges[h + 1]; c0 += d.tile_cols) tl.push_back(make_int2(c0, s.live_ranges[h + 1]));
                 d.n_tiles = static_cast<int>(tl.size());
                 d.tiles = reinterpret_cast<int2 *>(put(tl.data(), tl.size() * sizeof(int2)));
             }
@@ -3094,14 +3104,19 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
         if (nn_naive) return fail(GENPHI_ERR_ARG, "internal: an in-place WIDE step without a row kernel for its new x new block");
         if (!p->tun.stay_two_pass) {
             // 3S + 4S fused: new x dragged and its transpose in one pass over the parents' rows (rows_avg_t_kernel)
-            const size_t lds = 64 * (kFT + 1) * sizeof(float);
-            HIP_TRY(set_max_lds(reinterpret_cast<const void *>(rows_avg_t_kernel), lds));
+            const int ft = d.tile_cols;
+            const size_t lds = 64 * static_cast<size_t>(ft + 1) * sizeof(float);
+            HIP_TRY(set_max_lds(ft == 128 ? reinterpret_cast<const void *>(rows_avg_t_kernel<128>) : reinterpret_cast<const void *>(rows_avg_t_kernel<256>), lds));
             if (d.n_tiles > 0) {
                 const int gf = p->tun.stay_col_fastest ? 0 : 1;
                 const unsigned nct = static_cast<unsigned>(d.n_tiles);
                 dim3 gt(gf ? static_cast<unsigned>(n_gran) : nct, gf ? nct : static_cast<unsigned>(n_gran));
-                hipLaunchKernelGGL(rows_avg_t_kernel, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
-                                   d.blk_slot, d.tiles, cert_out, thr, gf, p->tun.stay_scalar_t ? 1 : 0);
+                if (ft == 128)
+                    hipLaunchKernelGGL(rows_avg_t_kernel<128>, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
+                                       d.blk_slot, d.tiles, cert_out, thr, gf, p->tun.stay_scalar_t ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(rows_avg_t_kernel<256>, gt, dim3(256), lds, p->stream, out, static_cast<long long>(s.ld), none, d.rowdesc + nd, n_new,
+                                       d.blk_slot, d.tiles, cert_out, thr, gf, p->tun.stay_scalar_t ? 1 : 0);
                 HIP_TRY(hipGetLastError());
             }
             return GENPHI_OK;

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN"]
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE"]
 
 
 def make_case(case):
@@ -76,6 +76,8 @@ def make_case(case):
         env["GENPHI_STAY_MIN_RATIO_PCT"] = str(int(r.choice([110, 150, 300])))       # in place with few dragged members too / only with many
     if r.random() < 0.2:
         pro = ind.copy() if r.random() < 0.5 else r.permutation(ind)[: max(3, len(ind) // int(r.integers(2, 6)))]
+    if r.random() < 0.3:
+        env["GENPHI_STAY_TILE"] = str(int(r.choice([128, 256])))                   # tile width of the fused in-place kernel
     if r.random() < 0.2:
         env["GENPHI_COLPERM_PLAIN"] = "1"                                         # the proband-order pass by the one-workgroup-per-row kernel
     if r.random() < 0.2:
