@@ -951,7 +951,7 @@ def test_wide_levels_stay_in_place(gen, oracle, monkeypatch):
                 stays += n_stay
                 for k, f in enumerate(flags):
                     if f[0] & 1:                     # in place: reads and writes by slot, the next step reads by slot too
-                        assert f[0] & 2 and flags[k + 1][0] & 2 and f[2] % 64 == 0 and f[3] % 64 == 0 and f[2] < f[1]
+                        assert f[0] & 2 and (k + 1 == len(flags) or flags[k + 1][0] & 2) and f[2] % 64 == 0 and f[3] % 64 == 0 and f[2] < f[1]      # (the proband step may stay in place too)
             for rep in range(4):                     # (the 3rd and 4th call of a >= 8-step sweep replay the captured graph)
                 _assert_equal(pl.compute(), want)
             _assert_equal(pl.compute(kernel=1), want)
@@ -1064,8 +1064,8 @@ def test_narrow_levels_stay_in_place(gen, oracle, monkeypatch):
                 stays += n_stay
                 for k, f in enumerate(flags):
                     if f[0] & 1:                     # in place: block assembly although a source row fits in LDS; the next step reads by slot
-                        assert modes[k] == 2 and sizes[k] <= 36_863 and f[0] & 2 and flags[k + 1][0] & 2 and modes[k + 1] == 2
-                assert modes[-1] != 2
+                        assert modes[k] == 2 and sizes[k] <= 36_863 and f[0] & 2 and (k + 1 == len(flags) or (flags[k + 1][0] & 2 and modes[k + 1] == 2))
+                assert modes[-1] != 2 or flags[-1][0] & 1      # (the proband step: a row kernel, or in place at the end of a run)
             for rep in range(4):
                 _assert_equal(pl.compute(), want)
             _assert_equal(pl.compute(kernel=1), want)

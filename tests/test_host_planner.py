@@ -340,7 +340,7 @@ def test_wide_runs_planned_in_place(monkeypatch):
     assert len(stay) >= 8 and all(modes[k] == 2 for k in stay)
     for k in stay:
         flags, P, p0, npad = slots[k]
-        assert flags & 2 and slots[k + 1][0] & 2 and modes[k + 1] == 2           # reads by slot; so does the next step, a WIDE one
+        assert flags & 2 and (k + 1 == len(slots) or (slots[k + 1][0] & 2 and modes[k + 1] == 2))      # reads by slot; so does the next step, a WIDE one (if any)
         assert P % 64 == 0 and p0 % 64 == 0 and npad % 64 == 0 and p0 < P
         assert npad >= sizes[k + 1] - both[k] and P >= sizes[k] + npad           # room for the source cut and the new members
         assert sizes[k + 1] >= 2 * (sizes[k + 1] - both[k])                      # worth it: at least as many dragged as new members
@@ -355,3 +355,51 @@ def test_wide_runs_planned_in_place(monkeypatch):
     # the memory guard: runs whose slot matrices need more than the given share of the plain level buffers are dropped
     s4, b4, m4, sl4 = plan_of(GENPHI_STAY_HEADROOM="3", GENPHI_STAY_MEM_PCT="101")
     assert (s4, b4, m4) == (sizes, both, modes) and all(f == (0, 0, 0, 0) for f in sl4)
+
+
+def test_narrow_runs_cost_model_and_proband_cut_in_place(monkeypatch):
+    """Round 4, planner side, no GPU.  (i) SURVEY.md 8(d)'s cfg3 (5 % of the parents from g-2): runs of SPLIT-width cuts stay in place
+    by the cost model -- 11 steps with the fixed cost per block-assembled step, 14 on bytes alone, none with GENPHI_STAY_NARROW=0 -- and
+    cut sizes / dragged counts do not depend on any of it.  (ii) a real genealogy with every individual a proband: the run goes THROUGH
+    the proband cut (the last step writes in place: flags & 1, nothing reads it), unless GENPHI_STAY_LAST=0 -- then the last step reads
+    by slot and compacts.  (iii) genea140 with its 140 probands keeps its row kernels."""
+    import numpy as np
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    knobs = ("GENPHI_STAY_NARROW", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_NO_STAY")
+
+    def plan_of(ped, pro, **env):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = gen.plan(ped, pro)
+        sizes, both = pl.levels()
+        modes = pl.step_modes()
+        slots = [pl.step_slots(k) for k in range(len(modes))]
+        pl.close()
+        return sizes, both, modes, slots
+
+    ind, fa, mo, sex, pro = synth.random_mating(100_000, 10_000, 20, skip_permille=50)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    sizes, both, modes, slots = plan_of(ped, pro)
+    stay = [k for k, f in enumerate(slots) if f[0] & 1]
+    assert max(sizes) == 20_540 and len(stay) == 11 and all(modes[k] == 2 and sizes[k] <= 36_863 for k in stay)
+    assert slots[stay[-1] + 1][0] == 2 and modes[stay[-1] + 1] == 2 and modes[-1] == 0      # the compacting step behind the run; the proband step FULL
+    assert all(sizes[k + 1] >= 2 * (sizes[k + 1] - both[k]) for k in stay)
+    s2, b2, m2, sl2 = plan_of(ped, pro, GENPHI_STAY_OVERHEAD_K="0")
+    assert (s2, b2) == (sizes, both) and sum(f[0] & 1 for f in sl2) == 14
+    s3, b3, m3, sl3 = plan_of(ped, pro, GENPHI_STAY_NARROW="0")
+    assert (s3, b3) == (sizes, both) and 2 not in m3 and all(f == (0, 0, 0, 0) for f in sl3)
+
+    ped = gen.genealogy(gen.genea140)
+    ids = np.asarray(ped.ind, dtype=np.int64)
+    sizes, both, modes, slots = plan_of(ped, ids)
+    assert sizes[-1] == 41_523 and slots[-1][0] & 1 and modes[-1] == 2                      # the proband step writes in place
+    assert sum(f[0] & 1 for f in slots) == 11 and slots[-1][1] >= sizes[-1]                 # slot capacity holds every proband
+    s4, b4, m4, sl4 = plan_of(ped, ids, GENPHI_STAY_LAST="0")
+    assert (s4, b4) == (sizes, both) and sl4[-1][0] == 2 and sum(f[0] & 1 for f in sl4) == 10   # ... or reads by slot and compacts
+    s5, b5, m5, sl5 = plan_of(ped, gen.pro(ped))
+    assert 2 not in m5                                                                      # 140 probands: 36-57 % of a cut is new
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
