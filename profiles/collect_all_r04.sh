@@ -7,7 +7,7 @@ TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${TAG}_artifacts; rm -rf "$O"; mkdir -p "$O"
 # traffic first (bench.py reads profiles/traffic_<workload>.json of the same kernel sources)
-for w in cfg4 cfg3s cfg3 cfg2 cfg5 cfg4o; do
+for w in cfg4 cfg3s cfg3 cfg2 cfg5 cfg4o cfg2all; do
   bash profiles/collect.sh $TAG $w > "$O/collect_$w.out" 2>&1
   python profiles/summarize.py $TAG $w >> "$O/collect_$w.out" 2>&1
   cp profiles/${TAG}_${w}_kernel_stats.csv profiles/${TAG}_${w}_levels.csv profiles/traffic_$w.json "$O/" 2>/dev/null
