@@ -549,10 +549,11 @@ def main():
                          "traffic_source": (f"profiles/traffic_{args.workload}.json (rocprofv3 PMC passes of this command; not re-collected by this run"
                                             + ("; STALE: collected with other kernel sources than this run's" if traffic_stale else "; same kernel sources as this run") + ")") if traffic else None,
                          "traffic_stale": traffic_stale,
-                         "real_traffic_GBs": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
+                         # (the measured traffic covers EVERY kernel of a sweep, the proband-order pass included: its time counts here)
+                         "real_traffic_GBs": (traffic * len(byt) / ((tot_ms + perm_ms / K) * 1e-3) / 1e9) if (traffic and tot_ms > 0) else None,
                          # the measured bytes against the peak: BELOW `frac` when levels stay in place (the dragged x dragged
                          # block counts in the algorithmic bytes but is never moved), above it when rows are re-read
-                         "real_traffic_frac": (traffic * len(byt) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and tot_ms > 0) else None,
+                         "real_traffic_frac": (traffic * len(byt) / ((tot_ms + perm_ms / K) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and tot_ms > 0) else None,
                          "launches_per_step": len(byt), "avg_launch_ms": tot_ms / max(len(byt), 1),
                          "largest_level": ({"step": int(np.argmax(byt)), "GB": max(byt) / 1e9, "ms": float(lvl_kernel[int(np.argmax(byt))]),
                                             "frac": max(byt) / (float(lvl_kernel[int(np.argmax(byt))]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
