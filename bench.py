@@ -465,7 +465,8 @@ def main():
             lvl_kernel[-1] -= perm_ms / K                 # the proband-order pass is a different kernel
         # the kernel that dominates the step: by accumulated time over the level steps of each kind
         modes = pl.step_modes()
-        names = {0: "level_full_kernel", 1: "level_split_fast_kernel", 2: "wide level (rows_compact_kernel + ...)"}
+        names = {0: "level_full_kernel", 1: "level_split_fast_kernel",
+                 2: "block assembly (in place: rows_avg_t_kernel + the new x new sub-step; compacting: rows_compact_kernel + transposes)"}
         if f64:                                            # row-staged Float64 kernel up to 10,239-wide cuts, per-entry kernel beyond
             names = {m: "level_full64_kernel / level_naive64_kernel" for m in (0, 1, 2)}
         by_kernel = {}
