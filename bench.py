@@ -516,7 +516,8 @@ def main():
         traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         # (the committed traffic files were collected with the default settings: not comparable under A/B hooks that change what moves)
-        if os.path.exists(tpath) and not f64 and not os.environ.get("GENPHI_NO_STAY"):
+        ab_hooks = [k for k in os.environ if k.startswith("GENPHI_") and k not in ("GENPHI_TRACE", "GENPHI_D2H_THREADS", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE")]
+        if os.path.exists(tpath) and not f64 and not ab_hooks:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
