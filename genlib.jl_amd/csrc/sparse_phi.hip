@@ -50,7 +50,6 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
-#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -286,13 +285,70 @@ long long pitch_of(long long n) { return ((n + 1) + 63) / 64 * 64; }
 
 struct Wave {
     int n_old = 0, n_new = 0, n_surv = 0;
-    std::vector<int4> par;        // per new individual: (father slot, mother slot, 2 rank + pro of the father, of the mother); slots in the old active list
-    std::vector<int> keep;        // old slots that survive the wave, ascending
-    std::vector<int> newpos;      // per old slot: its slot in the next list, or -1
-    std::vector<int2> meta_new;   // (2 rank + pro, processing index) of the new individuals, queue order
-    std::vector<int2> meta_old;   // ... of the old active list, slot order
-    size_t o_par = 0, o_keep = 0, o_newpos = 0, o_meta_new = 0, o_meta_old = 0;     // byte offsets in the device blob
+    // byte offsets in the device blob (the host image is written in place, wave by wave):
+    //   par       per new individual: (father slot, mother slot, 2 rank + pro of the father, of the mother); slots in the old active list
+    //   keep      old slots that survive the wave, ascending
+    //   newpos    per old slot: its slot in the next list, or -1
+    //   meta_new  (2 rank + pro, processing index) of the new individuals, queue order
+    //   meta_old  ... of the old active list, slot order
+    size_t o_par = 0, o_keep = 0, o_newpos = 0, o_meta_new = 0, o_meta_old = 0;
 };
+
+// Host memory of a result block, recycled through a one-slot cache: a fresh 16 MB block costs its page faults again on every call
+// (glibc maps and unmaps blocks of that size), 1-2 ms of a 9 ms call at 2,000 probands.  Uninitialised on purpose: every entry is written.
+struct FloatBlock {
+    float *p = nullptr;
+    size_t cap = 0;
+    FloatBlock() = default;
+    FloatBlock(const FloatBlock &) = delete;
+    FloatBlock &operator=(const FloatBlock &) = delete;
+    ~FloatBlock() { give_back(); }
+    float operator[](size_t i) const { return p[i]; }
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static FloatBlock *&slot() { static FloatBlock *s = nullptr; return s; }
+    bool take(size_t n)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu());
+            FloatBlock *&c = slot();
+            if (c && c->cap >= n && c->cap <= 4 * n + (1u << 20)) { p = c->p; cap = c->cap; c->p = nullptr; c->cap = 0; delete c; c = nullptr; return true; }
+        }
+        p = static_cast<float *>(std::malloc(std::max<size_t>(n, 1) * sizeof(float)));
+        cap = p ? n : 0;
+        return p != nullptr;
+    }
+    void give_back()
+    {
+        if (!p) return;
+        if (cap * sizeof(float) <= (size_t(1) << 30)) {
+            std::lock_guard<std::mutex> lock(mu());
+            FloatBlock *&c = slot();
+            if (!c) { c = new (std::nothrow) FloatBlock(); if (c) { c->p = p; c->cap = cap; p = nullptr; cap = 0; return; } }
+        }
+        std::free(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+// The device side of a call -- one pool allocation, the stream, the timing events -- kept for the next call on the same device
+// (one slot; pools above GENPHI_SPARSE_KEEP_MB, default 1024, are freed as before): hipMalloc + hipStreamCreate + hipFree with its
+// device-wide synchronisation + the event churn are 1.5-2 ms of a 9 ms call.
+struct DeviceSide {
+    char *pool = nullptr;
+    size_t bytes = 0;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    int device = -1;
+    void destroy()
+    {
+        if (pool) (void)hipFree(pool);
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+        pool = nullptr; bytes = 0; st = nullptr; ev.clear();
+    }
+};
+std::mutex g_side_mu;
+DeviceSide g_side_kept;
 
 }  // namespace
 
@@ -301,7 +357,7 @@ struct genphi_sparse {
     std::vector<int64_t> ids;                 // proband IDs, first-occurrence order
     std::vector<int> rank, proc;              // of each proband (rank in the pruned pedigree, processing index)
     std::vector<int> slot;                    // row / column of each proband in S
-    std::vector<float> S;                     // n_pro x n_pro: stored value of every pair of probands
+    FloatBlock S;                             // n_pro x n_pro: stored value of every pair of probands
     std::vector<int> stale_row_rank, stale_col_rank;   // entries that survive in a proband's dictionary
     std::vector<float> stale_val;
     std::unordered_map<int64_t, int> pos;     // ID -> index into ids
@@ -401,28 +457,35 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
 
     // ---- the queue, integers only: processing order and the processing index at which each
     //      non-proband is retired (src/compute.jl:336-345, :397-439) -----------------------------------
-    std::vector<int> proc(m, -1), retire(m, INT32_MAX), left(m, 0), order;
-    order.reserve(m);
+    // The reference pushes a child when its second known parent is processed (or its only one) and skips a second pop of the same
+    // individual; a countdown of known parents per child gives the same pushes in the same positions, so the processing order IS the
+    // queue array (a father who is also the mother lists the child twice in a row: two decrements, one push where the second would be).
+    // An individual is retired when its last child has been processed: retire = the largest processing index among its children,
+    // i.e. the last one written below (the reference counts the children down, src/compute.jl:425-433: same index).
+    std::vector<int> proc(m, -1), retire(m, INT32_MAX), order(m + 1);
     {
-        std::deque<int> queue;
+        std::vector<unsigned char> need(m);
         std::vector<std::pair<int64_t, int>> founders;
-        for (int u = 0; u < m; ++u) if (pf[u] < 0 && pm[u] < 0) founders.emplace_back(ind[orig[u]], u);
+        for (int u = 0; u < m; ++u) {
+            need[u] = static_cast<unsigned char>((pf[u] >= 0) + (pm[u] >= 0));
+            if (!need[u]) founders.emplace_back(ind[orig[u]], u);
+        }
         std::sort(founders.begin(), founders.end());             // founder(): IDs ascending
-        for (auto &e : founders) queue.push_back(e.second);
-        while (!queue.empty()) {
-            const int u = queue.front(); queue.pop_front();
-            if (proc[u] >= 0) continue;                          // (a child listed twice by one parent)
-            proc[u] = static_cast<int>(order.size());
-            order.push_back(u);
-            left[u] = nchild[u];
-            for (int par : {pf[u], pm[u]})
-                if (par >= 0 && !pro_flag[par] && --left[par] == 0) retire[par] = proc[u];
-            for (int k = cstart[u]; k < cstart[u + 1]; ++k) {
+        int tail = 0;
+        for (auto &e : founders) order[tail++] = e.second;
+        for (int head = 0; head < tail; ++head) {
+            const int u = order[head];
+            proc[u] = head;
+            if (pf[u] >= 0) retire[pf[u]] = head;
+            if (pm[u] >= 0) retire[pm[u]] = head;
+            for (int k = cstart[u], ke = cstart[u + 1]; k < ke; ++k) {
                 const int c = clist[k];
-                if (pf[c] >= 0 && pm[c] >= 0) { if (proc[pf[c]] >= 0 && proc[pm[c]] >= 0) queue.push_back(c); }
-                else queue.push_back(c);
+                order[tail] = c;                                 // (kept only if this was the child's last missing parent: no
+                tail += (--need[c] == 0);                        //  data-dependent branch, the coin flip costs more than the store)
             }
         }
+        order.resize(tail);
+        for (int u = 0; u < m; ++u) if (pro_flag[u]) retire[u] = INT32_MAX;      // probands stay to the end
     }
     if (static_cast<int>(order.size()) != m) return bail(GENPHI_ERR_ARG, "internal: the queue did not reach every individual");
     for (int k = 1; k < m; ++k)
@@ -433,8 +496,14 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     auto meta_of = [&](int u) { return make_int2(2 * (u + 1) + (pro_flag[u] ? 1 : 0), proc[u]); };
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     std::vector<Wave> waves;
-    std::vector<int> active;                                     // pruned indices, slot order
+    std::vector<int> active, next;                               // pruned indices, slot order
     std::vector<int> slot_of(m, -1);
+    // the host image of the device blob, written in place; the buffer is kept per thread between calls (no reallocation, no page
+    // faults in the steady state; padding and the unused tail of a wave's keep list are never read on the device)
+    static thread_local std::vector<char> blob_kept;
+    std::vector<char> &blob = blob_kept;
+    struct BlobTrim { std::vector<char> &b; ~BlobTrim() { if (b.capacity() > (size_t(64) << 20)) std::vector<char>().swap(b); } } blob_trim{blob};
+    if (blob.size() < 256) blob.resize(256);
     size_t max_mat = 64, max_T = 64, blob_bytes = 256;
     for (int b = 0; b < m;) {
         int e = b;
@@ -443,48 +512,40 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         w.n_old = static_cast<int>(active.size());
         w.n_new = e - b;
         const int last_proc = e - 1;
+        w.o_par = blob_bytes; blob_bytes += al(static_cast<size_t>(w.n_new) * sizeof(int4));
+        w.o_keep = blob_bytes; blob_bytes += al(static_cast<size_t>(w.n_old) * sizeof(int));        // (room for every old slot)
+        w.o_newpos = blob_bytes; blob_bytes += al(static_cast<size_t>(w.n_old) * sizeof(int));
+        w.o_meta_new = blob_bytes; blob_bytes += al(static_cast<size_t>(w.n_new) * sizeof(int2));
+        w.o_meta_old = blob_bytes; blob_bytes += al(static_cast<size_t>(w.n_old) * sizeof(int2));
+        if (blob.size() < blob_bytes) blob.resize(std::max(blob_bytes, blob.size() * 2));
+        int4 *par = reinterpret_cast<int4 *>(blob.data() + w.o_par);
+        int *keep = reinterpret_cast<int *>(blob.data() + w.o_keep), *newpos = reinterpret_cast<int *>(blob.data() + w.o_newpos);
+        int2 *meta_new = reinterpret_cast<int2 *>(blob.data() + w.o_meta_new), *meta_old = reinterpret_cast<int2 *>(blob.data() + w.o_meta_old);
         for (int k = b; k < e; ++k) {
             const int u = order[k];
             const int f = pf[u], mth = pm[u];
-            w.par.push_back(make_int4(f >= 0 ? slot_of[f] : w.n_old, mth >= 0 ? slot_of[mth] : w.n_old,
-                                      f >= 0 ? meta_of(f).x : 0, mth >= 0 ? meta_of(mth).x : 0));
-            w.meta_new.push_back(meta_of(u));
+            par[k - b] = make_int4(f >= 0 ? slot_of[f] : w.n_old, mth >= 0 ? slot_of[mth] : w.n_old, f >= 0 ? meta_of(f).x : 0, mth >= 0 ? meta_of(mth).x : 0);
+            meta_new[k - b] = meta_of(u);
         }
-        std::vector<int> next;
-        w.newpos.assign(w.n_old, -1);
-        w.meta_old.resize(w.n_old);
-        for (int s = 0; s < w.n_old; ++s) {
-            w.meta_old[s] = meta_of(active[s]);
-            if (retire[active[s]] > last_proc) { w.newpos[s] = static_cast<int>(next.size()); w.keep.push_back(s); next.push_back(active[s]); }
+        next.clear();
+        for (int sl = 0; sl < w.n_old; ++sl) {
+            const int u = active[sl];
+            meta_old[sl] = meta_of(u);
+            if (retire[u] > last_proc) { newpos[sl] = static_cast<int>(next.size()); keep[next.size()] = sl; slot_of[u] = static_cast<int>(next.size()); next.push_back(u); }
+            else newpos[sl] = -1;
         }
         w.n_surv = static_cast<int>(next.size());
-        for (int k = b; k < e; ++k) next.push_back(order[k]);
-        for (size_t s = 0; s < next.size(); ++s) slot_of[next[s]] = static_cast<int>(s);
+        for (int k = b; k < e; ++k) { slot_of[order[k]] = static_cast<int>(next.size()); next.push_back(order[k]); }
         max_mat = std::max(max_mat, static_cast<size_t>((next.size() + 1) * pitch_of(static_cast<long long>(next.size()))));
         max_T = std::max(max_T, static_cast<size_t>(w.n_new) * static_cast<size_t>(pitch_of(w.n_old)));
         R->max_active = std::max<int64_t>(R->max_active, static_cast<int64_t>(next.size()));
         R->wave_bytes.push_back(4.0 * (static_cast<double>(w.n_old) * w.n_old + static_cast<double>(next.size()) * next.size()));
-        w.o_par = blob_bytes; blob_bytes += al(w.par.size() * sizeof(int4));
-        w.o_keep = blob_bytes; blob_bytes += al(w.keep.size() * sizeof(int));
-        w.o_newpos = blob_bytes; blob_bytes += al(w.newpos.size() * sizeof(int));
-        w.o_meta_new = blob_bytes; blob_bytes += al(w.meta_new.size() * sizeof(int2));
-        w.o_meta_old = blob_bytes; blob_bytes += al(w.meta_old.size() * sizeof(int2));
         active.swap(next);
-        waves.push_back(std::move(w));
+        waves.push_back(w);
         b = e;
     }
     // the final active list is exactly the probands
     if (static_cast<int64_t>(active.size()) != R->n_pro) return bail(GENPHI_ERR_ARG, "internal: final active set is not the proband set");
-    std::vector<char> blob(blob_bytes, 0);
-    for (Wave &w : waves) {
-        std::memcpy(blob.data() + w.o_par, w.par.data(), w.par.size() * sizeof(int4));
-        std::memcpy(blob.data() + w.o_keep, w.keep.data(), w.keep.size() * sizeof(int));
-        std::memcpy(blob.data() + w.o_newpos, w.newpos.data(), w.newpos.size() * sizeof(int));
-        std::memcpy(blob.data() + w.o_meta_new, w.meta_new.data(), w.meta_new.size() * sizeof(int2));
-        std::memcpy(blob.data() + w.o_meta_old, w.meta_old.data(), w.meta_old.size() * sizeof(int2));
-        std::vector<int4>().swap(w.par); std::vector<int>().swap(w.keep); std::vector<int>().swap(w.newpos);
-        std::vector<int2>().swap(w.meta_new); std::vector<int2>().swap(w.meta_old);
-    }
     for (double x : R->wave_bytes) R->algorithmic_bytes += x;
 
     mark("waves, blob image");
@@ -497,29 +558,47 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     char *d_blob = nullptr;
     int2 *d_src = nullptr;
     int *d_cnt = nullptr;
-    hipStream_t st = nullptr;
-    std::vector<hipEvent_t> ev;
-    char *pool = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(pool);
-        pool = nullptr;
+    DeviceSide side;
+    {   // the device side kept by the previous call on this device, if any
+        int dev_now = 0;
+        (void)hipGetDevice(&dev_now);
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        if (g_side_kept.st && g_side_kept.device == dev_now) { side = std::move(g_side_kept); g_side_kept = DeviceSide(); }
+        side.device = dev_now;
+    }
+    hipStream_t &st = side.st;
+    std::vector<hipEvent_t> &ev = side.ev;
+    char *&pool = side.pool;
+    static const size_t keep_bytes = [] { const char *e = std::getenv("GENPHI_SPARSE_KEEP_MB"); return static_cast<size_t>(e ? std::max(0L, std::atol(e)) : 1024L) << 20; }();
+    auto cleanup = [&]() {                                        // on an error: everything goes
+        side.destroy();
         dM[0] = dM[1] = dT = d_sval = nullptr; d_blob = nullptr; d_src = nullptr; d_cnt = nullptr;
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        ev.clear();
-        if (st) (void)hipStreamDestroy(st);
-        st = nullptr;
+    };
+    auto release = [&]() {                                        // at the end of a call: kept for the next one if the slot is free
+        if (side.bytes <= keep_bytes && keep_bytes > 0) {
+            std::lock_guard<std::mutex> lock(g_side_mu);
+            if (!g_side_kept.st) { g_side_kept = std::move(side); side = DeviceSide(); return; }
+        }
+        side.destroy();
     };
 #define SP_GO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return bail(GENPHI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    // (GENPHI_SPARSE_STALE_CAP: the first sweep's room for entries that outlive their columns -- tests force the second sweep with it)
     int stale_cap = 1 << 16, n_stale = 0;
+    if (const char *e = std::getenv("GENPHI_SPARSE_STALE_CAP")) stale_cap = std::max(1, std::atoi(e));
     const bool timed = waves.size() <= 4096;
     size_t max_lds = 0;
     for (const Wave &w : waves) if (w.n_new > 1 && w.n_old <= 36864) max_lds = std::max(max_lds, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
     for (int attempt = 0; attempt < 2; ++attempt) {               // (a second sweep only if the list of outliving entries overflowed)
-        SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        {   // ONE allocation (and one free) for the two matrices, T, the index blob and the outliving-entry lists
+        if (!st) SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        {   // ONE allocation for the two matrices, T, the index blob and the outliving-entry lists
             const size_t b_M = al(max_mat * sizeof(float)), b_T = al(max_T * sizeof(float)), b_blob = al(blob_bytes);
             const size_t b_sv = al(static_cast<size_t>(stale_cap) * sizeof(float)), b_src = al(static_cast<size_t>(stale_cap) * sizeof(int2));
-            SP_GO(hipMalloc(reinterpret_cast<void **>(&pool), 2 * b_M + b_T + b_blob + b_sv + b_src + 256));
+            const size_t need = 2 * b_M + b_T + b_blob + b_sv + b_src + 256;
+            if (side.bytes < need) {
+                if (pool) { (void)hipFree(pool); pool = nullptr; side.bytes = 0; }
+                SP_GO(hipMalloc(reinterpret_cast<void **>(&pool), need));
+                side.bytes = need;
+            }
             dM[0] = reinterpret_cast<float *>(pool); dM[1] = reinterpret_cast<float *>(pool + b_M);
             dT = reinterpret_cast<float *>(pool + 2 * b_M);
             d_blob = pool + 2 * b_M + b_T;
@@ -532,7 +611,10 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         SP_GO(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
         if (max_lds > 48 * 1024)
             SP_GO(hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_newnew_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)));
-        if (timed) { ev.resize(waves.size() + 1); for (hipEvent_t &e : ev) SP_GO(hipEventCreate(&e)); SP_GO(hipEventRecord(ev[0], st)); }
+        if (timed) {
+            while (ev.size() < waves.size() + 1) { hipEvent_t e; SP_GO(hipEventCreate(&e)); ev.push_back(e); }
+            SP_GO(hipEventRecord(ev[0], st));
+        }
         StaleOut so; so.cnt = d_cnt; so.cap = stale_cap; so.rc = d_src; so.val = d_sval;
         long long ld_cur = pitch_of(0);
         int cur = 0;
@@ -575,16 +657,15 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         mark("sweep done");
         if (n_stale > stale_cap) {                                // more entries outlive their columns than the list holds: once more, sized exactly
             if (attempt == 1 || n_stale > (1 << 28)) { cleanup(); return bail(GENPHI_ERR_ALLOC, "genphi_sparse_phi: too many entries outlive their columns"); }
-            stale_cap = n_stale;
-            cleanup();
+            stale_cap = n_stale;                                  // (the pool grows at the top of the second attempt)
             continue;
         }
         // ---- results: the proband x proband block, the remembered entries, the timings ------------------------
         const int64_t N = R->n_pro;
-        R->S.resize(static_cast<size_t>(N * N));
+        if (!R->S.take(static_cast<size_t>(N * N))) { cleanup(); return bail(GENPHI_ERR_ALLOC, "out of memory"); }
         if (N > 0) {
             // through a pinned staging buffer kept for the life of the process (a 2D copy into pageable memory runs at ~6 GB/s:
-            // 2.7 of the 12 ms of a call at 2,000 probands)
+            // 2.7 of the 12 ms of a call at 2,000 probands), in four row bands so that the host copy of a band runs under the next one's transfer
             static std::mutex pin_mu;
             static void *pin = nullptr;
             static size_t pin_bytes = 0;
@@ -596,11 +677,25 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
                 if (hipHostMalloc(&pin, need, hipHostMallocDefault) == hipSuccess) pin_bytes = need; else { (void)hipGetLastError(); pin = nullptr; }
             }
             if (pin) {
-                SP_GO(hipMemcpy2DAsync(pin, N * sizeof(float), dM[cur], ld_cur * sizeof(float), N * sizeof(float), N, hipMemcpyDeviceToHost, st));
-                SP_GO(hipStreamSynchronize(st));
-                std::memcpy(R->S.data(), pin, need);
+                constexpr int kBands = 4;
+                const size_t ev0 = timed ? waves.size() + 1 : 0;             // (after the waves' timing events)
+                while (ev.size() < ev0 + kBands) { hipEvent_t e; SP_GO(hipEventCreate(&e)); ev.push_back(e); }
+                hipEvent_t *band_ev = ev.data() + ev0;
+                const int64_t rows_band = (N + kBands - 1) / kBands;
+                for (int bnd = 0; bnd < kBands; ++bnd) {
+                    const int64_t r0 = bnd * rows_band, r1 = std::min<int64_t>(N, r0 + rows_band);
+                    if (r1 > r0)
+                        SP_GO(hipMemcpy2DAsync(static_cast<char *>(pin) + r0 * N * sizeof(float), N * sizeof(float), dM[cur] + r0 * ld_cur, ld_cur * sizeof(float),
+                                               N * sizeof(float), r1 - r0, hipMemcpyDeviceToHost, st));
+                    SP_GO(hipEventRecord(band_ev[bnd], st));
+                }
+                for (int bnd = 0; bnd < kBands; ++bnd) {
+                    const int64_t r0 = bnd * rows_band, r1 = std::min<int64_t>(N, r0 + rows_band);
+                    SP_GO(hipEventSynchronize(band_ev[bnd]));
+                    if (r1 > r0) std::memcpy(R->S.p + r0 * N, static_cast<char *>(pin) + r0 * N * sizeof(float), static_cast<size_t>(r1 - r0) * N * sizeof(float));
+                }
             } else {
-                SP_GO(hipMemcpy2D(R->S.data(), N * sizeof(float), dM[cur], ld_cur * sizeof(float), N * sizeof(float), N, hipMemcpyDeviceToHost));
+                SP_GO(hipMemcpy2D(R->S.p, N * sizeof(float), dM[cur], ld_cur * sizeof(float), N * sizeof(float), N, hipMemcpyDeviceToHost));
             }
         }
         if (n_stale) {
@@ -622,8 +717,8 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             for (size_t wi = 0; wi < waves.size(); ++wi) SP_GO(hipEventElapsedTime(&R->wave_ms[wi], ev[wi], ev[wi + 1]));
         }
         mark("results to host");
-        cleanup();
-        mark("free");
+        release();
+        mark("device side kept / freed");
         break;
     }
 #undef SP_GO

@@ -1292,7 +1292,7 @@ def test_sparse_phi_kinship_matrix(gen, oracle):
     _sparse_check(gen, oracle, *g, pro=gen.pro(ped)[:25])
 
 
-def test_sparse_phi_unsorted_ranks(gen, oracle):
+def test_sparse_phi_unsorted_ranks(gen, oracle, capfd):
     """gen.genealogy(...; sort=false) (src/create.jl:131,161): the rank is the file position, so an
     individual of an earlier depth can carry the larger rank.  sparse_phi then (i) finds fewer kinships
     (lookups use (smaller rank, larger rank), stores use (earlier, later): src/compute.jl:366-394) and
@@ -1322,6 +1322,26 @@ def test_sparse_phi_unsorted_ranks(gen, oracle):
             a, b = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=True)
             n_cross += K.info()[1] != a.info()[1]
     assert n_cross >= 3                                                     # the file order really changes what is stored
+    # more outliving entries than the first sweep's list holds: the sweep runs a second time with the list sized exactly, on the same
+    # pool and stream; then ordinary calls again on the device side that call left behind, smaller and larger than it
+    ind, fa, mo, sex, pro = synth.random_mating(1500, 100, 12, skip_permille=200, seed=9)
+    i2, f2, m2, s2 = synth.parents_first_shuffle(ind, fa, mo, sex, seed=3)
+    extra = i2[np.random.default_rng(3).integers(0, len(i2), 12)]
+    p = np.concatenate([pro[::2], extra])
+    K0, _ = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=False)
+    os.environ["GENPHI_SPARSE_STALE_CAP"] = "1"
+    os.environ["GENPHI_TRACE"] = "1"
+    capfd.readouterr()
+    try:
+        K1, _ = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=False)
+    finally:
+        del os.environ["GENPHI_SPARSE_STALE_CAP"], os.environ["GENPHI_TRACE"]
+    assert capfd.readouterr().err.count("sweep done") == 2                  # the list overflowed, the sweep ran twice
+    assert K1.info() == K0.info() and all(np.array_equal(x, y) for x, y in zip(K1.entries(), K0.entries()))
+    for args in [(300, 30, 5), (4000, 300, 9), (600, 60, 6), (4000, 300, 9)]:
+        q = synth.random_mating(*args, seed=21)
+        held = [_sparse_check(gen, oracle, *q[:4], q[4], sort=True)[0] for _ in range(2)]      # two results alive at once: separate host blocks
+        assert held[0].info() == held[1].info()
     g = oracle.read_tsv(gen.genea140)                                       # genea140 in its own file order, and shuffled parents-first
     ped = gen.genealogy(gen.genea140, sort=False)
     assert np.array_equal(ped.ind, g[0])
