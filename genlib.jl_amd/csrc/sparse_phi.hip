@@ -254,6 +254,72 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
     else newnew_partners(trow, a, n_old, n_new, ma, par, meta_new, orow, so);
 }
 
+// One new row end to end (round 4, second pass): T[a][.] is only ever read by row a's own new x new entries, so the row is built in
+// LDS from the two parent rows of the old matrix (the same rows_entry as sparse_rows_body), its surviving columns go straight to the
+// next matrix, and the partners b > a gather from LDS -- T never touches HBM (one write and one read of n_new x n_old floats less per
+// wave) and a wave is two launches.  Workgroups past the n_new rows compact survivors x survivors as before.  Old sets of up to 36,864
+// members (144 KB of LDS); wider ones keep the two-kernel form above.
+__global__ void __launch_bounds__(256)
+sparse_row_fused_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
+                        const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ next, long long ld_next,
+                        int n_surv, StaleOut so, const int *__restrict__ keep)
+{
+    extern __shared__ float srow[];
+    if (static_cast<int>(blockIdx.x) >= n_new) {
+        const int c = blockIdx.x - n_new;
+        sparse_compact_body(c % n_surv, c / n_surv, M, ld, keep, n_surv, next, ld_next);
+        return;
+    }
+    const int a = blockIdx.x;
+    const int4 p = par[a];
+    const bool hasF = p.x != n_old, hasM = p.y != n_old;             // workgroup-uniform
+    const int2 mf = hasF ? meta[p.x] : make_int2(0, 0), mm = hasM ? meta[p.y] : make_int2(0, 0);
+    const int2 mi = meta_new[a];
+    const float *rowF = M + (long long)(hasF ? p.x : 0) * ld, *rowM = M + (long long)(hasM ? p.y : 0) * ld;
+    float *orow_s = next + (long long)(n_surv + a) * ld_next;
+    const int nquad = (n_old + 3) / 4;
+    for (int k0 = threadIdx.x; k0 < nquad; k0 += 2 * 256) {           // two quads per lane: four 16-byte matrix loads in flight
+        float4 a4[2], b4[2];
+        int4 m01[2], m23[2], np4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q0 = 4 * min(k0 + u * 256, nquad - 1);
+            a4[u] = *reinterpret_cast<const float4 *>(rowF + q0);
+            b4[u] = *reinterpret_cast<const float4 *>(rowM + q0);
+            m01[u] = *reinterpret_cast<const int4 *>(meta + q0); m23[u] = *reinterpret_cast<const int4 *>(meta + q0 + 2);
+            np4[u] = *reinterpret_cast<const int4 *>(newpos + q0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (k0 + u * 256 >= nquad) continue;
+            const int q0 = 4 * (k0 + u * 256);
+            const float v0 = rows_entry(q0, n_old, make_int2(m01[u].x, m01[u].y), a4[u].x, b4[u].x, hasF, hasM, p.x, p.y, mf, mm);
+            const float v1 = rows_entry(q0 + 1, n_old, make_int2(m01[u].z, m01[u].w), a4[u].y, b4[u].y, hasF, hasM, p.x, p.y, mf, mm);
+            const float v2 = rows_entry(q0 + 2, n_old, make_int2(m23[u].x, m23[u].y), a4[u].z, b4[u].z, hasF, hasM, p.x, p.y, mf, mm);
+            const float v3 = rows_entry(q0 + 3, n_old, make_int2(m23[u].z, m23[u].w), a4[u].w, b4[u].w, hasF, hasM, p.x, p.y, mf, mm);
+            *reinterpret_cast<float4 *>(srow + q0) = make_float4(v0, v1, v2, v3);
+#define GENPHI_SPARSE_EMIT(U, V, MQX, NP)                                                                                         \
+            if (q0 + U < n_old) {                                                                                                 \
+                if (NP >= 0) orow_s[NP] = V;                                                                                      \
+                if (V > 0.f && !(mi.x & 1) && (MQX & 1) && MQX > mi.x) stale_append(so.cnt, so.cap, so.rc, so.val, MQX >> 1, mi.x >> 1, V); \
+            }
+            GENPHI_SPARSE_EMIT(0, v0, m01[u].x, np4[u].x)
+            GENPHI_SPARSE_EMIT(1, v1, m01[u].z, np4[u].y)
+            GENPHI_SPARSE_EMIT(2, v2, m23[u].x, np4[u].z)
+            GENPHI_SPARSE_EMIT(3, v3, m23[u].z, np4[u].w)
+#undef GENPHI_SPARSE_EMIT
+        }
+    }
+    __syncthreads();
+    float *orow = orow_s + n_surv;
+    if (threadIdx.x == 0) {
+        double cf = 0.5;
+        if (hasF && hasM && (p.x == p.y || key_found(mf, mm))) cf += static_cast<double>(half32(rowF[p.y]));
+        orow[a] = static_cast<float>(cf);
+    }
+    newnew_partners(static_cast<const float *>(srow), a, n_old, n_new, mi, par, meta_new, orow, so);
+}
+
 // next[c][r] = next[r][c] for the new rows r >= n_surv and the columns c < n_surv (survivors x new) or c > r
 // (lower triangle of new x new); 64 x 64 tiles through LDS, both sides coalesced
 __global__ void __launch_bounds__(256)
@@ -587,7 +653,8 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     if (const char *e = std::getenv("GENPHI_SPARSE_STALE_CAP")) stale_cap = std::max(1, std::atoi(e));
     const bool timed = waves.size() <= 4096;
     size_t max_lds = 0;
-    for (const Wave &w : waves) if (w.n_new > 1 && w.n_old <= 36864) max_lds = std::max(max_lds, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
+    const bool no_fused = std::getenv("GENPHI_SPARSE_NO_FUSED") != nullptr;      // (A/B and tests: the two-kernel form of a wave)
+    for (const Wave &w : waves) if (w.n_new > 0 && w.n_old <= 36864) max_lds = std::max(max_lds, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
     for (int attempt = 0; attempt < 2; ++attempt) {               // (a second sweep only if the list of outliving entries overflowed)
         if (!st) SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         {   // ONE allocation for the two matrices, T, the index blob and the outliving-entry lists
@@ -609,8 +676,10 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
         mark("stream, allocation");
         SP_GO(hipMemcpyAsync(d_blob, blob.data(), blob_bytes, hipMemcpyHostToDevice, st));
         SP_GO(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-        if (max_lds > 48 * 1024)
+        if (max_lds > 48 * 1024) {
             SP_GO(hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_newnew_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)));
+            SP_GO(hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_row_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)));
+        }
         if (timed) {
             while (ev.size() < waves.size() + 1) { hipEvent_t e; SP_GO(hipEventCreate(&e)); ev.push_back(e); }
             SP_GO(hipEventRecord(ev[0], st));
@@ -625,7 +694,14 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             const int4 *d_par = reinterpret_cast<const int4 *>(d_blob + w.o_par);
             const int *d_keep = reinterpret_cast<const int *>(d_blob + w.o_keep), *d_newpos = reinterpret_cast<const int *>(d_blob + w.o_newpos);
             const int2 *d_meta_new = reinterpret_cast<const int2 *>(d_blob + w.o_meta_new), *d_meta_old = reinterpret_cast<const int2 *>(d_blob + w.o_meta_old);
-            {   // the new rows against the old members + survivors x survivors: ONE launch (both only read the old matrix)
+            const bool fused = !no_fused && w.n_new > 0 && w.n_old <= 36864;
+            if (fused) {   // a new row end to end per workgroup (T stays in LDS) + survivors x survivors: ONE launch
+                const long long cb = w.n_surv > 0 ? static_cast<long long>(w.n_surv) * ((w.n_surv + 2047) / 2048) : 0;
+                const size_t lds = std::max<size_t>(16, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
+                hipLaunchKernelGGL(sparse_row_fused_kernel, dim3(static_cast<unsigned>(w.n_new + cb)), dim3(256), lds, st, dM[cur], ld_cur, d_meta_old, w.n_old,
+                                   d_par, d_meta_new, w.n_new, d_newpos, dM[cur ^ 1], ld_next, w.n_surv, so, d_keep);
+                SP_GO(hipGetLastError());
+            } else {   // the new rows against the old members + survivors x survivors: ONE launch (both only read the old matrix)
                 const int rows_bx = (w.n_new > 0 && w.n_old > 0) ? (w.n_new + kRowsPerBlock - 1) / kRowsPerBlock : 0;
                 const int rows_by = rows_bx ? (w.n_old + 1023) / 1024 : 0;
                 const long long cb = w.n_surv > 0 ? static_cast<long long>(w.n_surv) * ((w.n_surv + 2047) / 2048) : 0;
@@ -638,11 +714,13 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
                 }
             }
             if (w.n_new > 0) {
-                const int lds_floats = w.n_old <= 36864 ? (w.n_old + 3) / 4 * 4 : 0;
-                hipLaunchKernelGGL(sparse_newnew_kernel, dim3(static_cast<unsigned>(w.n_new)), dim3(256), static_cast<size_t>(lds_floats) * sizeof(float), st,
-                                   dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new, dT, ldT, w.n_new, w.n_old > 0 ? lds_floats : 0,
-                                   dM[cur ^ 1], ld_next, w.n_surv, so);
-                SP_GO(hipGetLastError());
+                if (!fused) {
+                    const int lds_floats = w.n_old <= 36864 ? (w.n_old + 3) / 4 * 4 : 0;
+                    hipLaunchKernelGGL(sparse_newnew_kernel, dim3(static_cast<unsigned>(w.n_new)), dim3(256), static_cast<size_t>(lds_floats) * sizeof(float), st,
+                                       dM[cur], ld_cur, d_meta_old, w.n_old, d_par, d_meta_new, dT, ldT, w.n_new, w.n_old > 0 ? lds_floats : 0,
+                                       dM[cur ^ 1], ld_next, w.n_surv, so);
+                    SP_GO(hipGetLastError());
+                }
                 dim3 grid(static_cast<unsigned>((n_next + 63) / 64), static_cast<unsigned>((w.n_new + 63) / 64));
                 hipLaunchKernelGGL(sparse_mirror_kernel, grid, dim3(256), 0, st, dM[cur ^ 1], ld_next, w.n_surv, n_next);
                 SP_GO(hipGetLastError());

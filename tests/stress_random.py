@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE"]
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE", "GENPHI_SPARSE_NO_FUSED"]
 
 
 def make_case(case):
@@ -84,6 +84,8 @@ def make_case(case):
         env["GENPHI_STAY_LAST"] = "0"                                             # the proband cut never stays in place
     if r.random() < 0.25:
         env["GENPHI_STAY_SCALAR_T"] = "1"                                         # the fused in-place kernel's transposed tile by 4-byte stores
+    if r.random() < 0.3:
+        env["GENPHI_SPARSE_NO_FUSED"] = "1"                                       # sparse_phi: a wave as rows + new x new kernels with T in HBM
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env
 
 
