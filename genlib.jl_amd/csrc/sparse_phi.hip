@@ -25,15 +25,15 @@
 // key, else 0 (src/compute.jl:366-390 looks up phi[min rank][max rank], :392-394 stores under
 // [rank of the live one][rank of the new one]).  The live set is a dense matrix in HBM ("active
 // matrix"), rebuilt after every wave as [survivors..., new...] (retired parents leave), like the cuts
-// of the dense path with other membership rules.  Per wave, all streaming, no host round trip (the first two passes are ONE launch,
-// sparse_rows_compact_kernel: both only read the old matrix):
-//   sparse_rows_body       the new rows against the old members: the two parent rows of the active matrix
-//                          streamed with 16-byte loads, masked by the key rule, written twice -- whole
-//                          (T, for the new x new block) and compacted into the next matrix (new x survivors)
-//   sparse_compact_body    survivors x survivors: a stream compaction of the old matrix
-//   sparse_newnew_kernel   new x new, upper triangle in queue order: row j of T staged in LDS, two gathers
-//                          per entry; the self kinships
-//   sparse_mirror_kernel   survivors x new and the lower triangle by 64 x 64 tile transposition
+// of the dense path with other membership rules.  Per wave, all streaming, no host round trip, TWO launches:
+//   sparse_row_fused_kernel  one workgroup per new row i: T[i][.] built in LDS from the two parent rows of the active matrix
+//                            (16-byte loads, masked by the key rule), its surviving columns written straight into the next
+//                            matrix (new x survivors), then new x new for the later partners j > i by two LDS gathers per
+//                            entry, and the self kinship; T never exists in HBM.  The workgroups after the rows compact
+//                            survivors x survivors (a stream compaction of the old matrix: both parts only read it)
+//   sparse_mirror_kernel     survivors x new and the lower triangle by 64 x 64 tile transposition
+// (old sets above 36,864 members -- a T row beyond 144 KB of LDS -- take the round-3 form: sparse_rows_compact_kernel writes T to
+// HBM, sparse_newnew_kernel gathers from it; GENPHI_SPARSE_NO_FUSED=1 forces that form.)
 // The host simulates the queue once (integers only: processing order, waves, the wave after which
 // every individual retires) and uploads every wave's index arrays in ONE blob before the sweep; the
 // sweep is one stream of launches with a single synchronisation at its end.
@@ -154,6 +154,7 @@ sparse_rows_body(int bx, int by, const float *__restrict__ M, long long ld, cons
 }
 
 // survivors x survivors: next[r][c] = M[keep[r]][keep[c]] (keep ascending: a stream compaction)
+template <int NT = 256>
 __device__ __forceinline__ void
 sparse_compact_body(int bx, int by, const float *__restrict__ M, long long ld, const int *__restrict__ keep, int n_surv, float *__restrict__ next,
                     long long ld_next)
@@ -161,16 +162,16 @@ sparse_compact_body(int bx, int by, const float *__restrict__ M, long long ld, c
     constexpr int U = 8;
     const float *src = M + (long long)keep[bx] * ld;
     float *dst = next + (long long)bx * ld_next;
-    const int c0 = by * (256 * U) + threadIdx.x;
+    const int c0 = by * (NT * U) + threadIdx.x;
     int q[U];
     float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = keep[min(c0 + u * 256, n_surv - 1)];
+    for (int u = 0; u < U; ++u) q[u] = keep[min(c0 + u * NT, n_surv - 1)];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = src[q[u]];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int c = c0 + u * 256;
+        const int c = c0 + u * NT;
         if (c < n_surv) dst[c] = v[u];
     }
 }
@@ -199,17 +200,17 @@ sparse_rows_compact_kernel(const float *__restrict__ M, long long ld, const int2
 //   next[n_surv + a][n_surv + a] = RN32(1/2 + L(f_a, m_a)/2)
 // Row a of T is staged in LDS when it fits (lds_floats >= n_old), else gathered from L2.
 // partners b > a of new row a; `src` = T[a][.] (global) or its LDS copy -- two instantiations, so that neither gathers through FLAT loads
-template <typename Src>
+template <int NT = 256, typename Src>
 __device__ __forceinline__ void newnew_partners(Src src, int a, int n_old, int n_new, int2 ma, const int4 *__restrict__ par,
                                                 const int2 *__restrict__ meta_new, float *__restrict__ orow, const StaleOut &so)
 {
-    for (int b0 = a + 1 + threadIdx.x; b0 < n_new; b0 += 4 * 256) {
+    for (int b0 = a + 1 + threadIdx.x; b0 < n_new; b0 += 4 * NT) {
         int4 p[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = par[min(b0 + u * 256, n_new - 1)];
+        for (int u = 0; u < 4; ++u) p[u] = par[min(b0 + u * NT, n_new - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int b = b0 + u * 256;
+            const int b = b0 + u * NT;
             if (b >= n_new) continue;
             // the parents left the queue before a (an earlier wave): T[a][parent] sits under (rank parent, rank a),
             // which the lookup (smaller rank, larger rank) finds only when rank parent < rank a
@@ -259,7 +260,16 @@ sparse_newnew_kernel(const float *__restrict__ M, long long ld, const int2 *__re
 // next matrix, and the partners b > a gather from LDS -- T never touches HBM (one write and one read of n_new x n_old floats less per
 // wave) and a wave is two launches.  Workgroups past the n_new rows compact survivors x survivors as before.  Old sets of up to 36,864
 // members (144 KB of LDS); wider ones keep the two-kernel form above.
-__global__ void __launch_bounds__(256)
+// (measured: 1 quad per lane and trip with 256 threads beats 2 and 4 quads and 512 threads -- fewer registers, more resident
+// workgroups: r04_ab_sparse_phi_fused_row_quads_per_lane_and_threads.out)
+#ifndef GENPHI_SPARSE_QUADS_PER_LANE
+#define GENPHI_SPARSE_QUADS_PER_LANE 1
+#endif
+#ifndef GENPHI_SPARSE_ROW_THREADS
+#define GENPHI_SPARSE_ROW_THREADS 256
+#endif
+constexpr int kRowThreads = GENPHI_SPARSE_ROW_THREADS;
+__global__ void __launch_bounds__(kRowThreads)
 sparse_row_fused_kernel(const float *__restrict__ M, long long ld, const int2 *__restrict__ meta, int n_old, const int4 *__restrict__ par,
                         const int2 *__restrict__ meta_new, int n_new, const int *__restrict__ newpos, float *__restrict__ next, long long ld_next,
                         int n_surv, StaleOut so, const int *__restrict__ keep)
@@ -267,7 +277,7 @@ sparse_row_fused_kernel(const float *__restrict__ M, long long ld, const int2 *_
     extern __shared__ float srow[];
     if (static_cast<int>(blockIdx.x) >= n_new) {
         const int c = blockIdx.x - n_new;
-        sparse_compact_body(c % n_surv, c / n_surv, M, ld, keep, n_surv, next, ld_next);
+        sparse_compact_body<kRowThreads>(c % n_surv, c / n_surv, M, ld, keep, n_surv, next, ld_next);
         return;
     }
     const int a = blockIdx.x;
@@ -278,21 +288,22 @@ sparse_row_fused_kernel(const float *__restrict__ M, long long ld, const int2 *_
     const float *rowF = M + (long long)(hasF ? p.x : 0) * ld, *rowM = M + (long long)(hasM ? p.y : 0) * ld;
     float *orow_s = next + (long long)(n_surv + a) * ld_next;
     const int nquad = (n_old + 3) / 4;
-    for (int k0 = threadIdx.x; k0 < nquad; k0 += 2 * 256) {           // two quads per lane: four 16-byte matrix loads in flight
-        float4 a4[2], b4[2];
-        int4 m01[2], m23[2], np4[2];
+    constexpr int QL = GENPHI_SPARSE_QUADS_PER_LANE;                  // quads per lane and trip: 2 x QL 16-byte matrix loads in flight
+    for (int k0 = threadIdx.x; k0 < nquad; k0 += QL * kRowThreads) {
+        float4 a4[QL], b4[QL];
+        int4 m01[QL], m23[QL], np4[QL];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q0 = 4 * min(k0 + u * 256, nquad - 1);
+        for (int u = 0; u < QL; ++u) {
+            const int q0 = 4 * min(k0 + u * kRowThreads, nquad - 1);
             a4[u] = *reinterpret_cast<const float4 *>(rowF + q0);
             b4[u] = *reinterpret_cast<const float4 *>(rowM + q0);
             m01[u] = *reinterpret_cast<const int4 *>(meta + q0); m23[u] = *reinterpret_cast<const int4 *>(meta + q0 + 2);
             np4[u] = *reinterpret_cast<const int4 *>(newpos + q0);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (k0 + u * 256 >= nquad) continue;
-            const int q0 = 4 * (k0 + u * 256);
+        for (int u = 0; u < QL; ++u) {
+            if (k0 + u * kRowThreads >= nquad) continue;
+            const int q0 = 4 * (k0 + u * kRowThreads);
             const float v0 = rows_entry(q0, n_old, make_int2(m01[u].x, m01[u].y), a4[u].x, b4[u].x, hasF, hasM, p.x, p.y, mf, mm);
             const float v1 = rows_entry(q0 + 1, n_old, make_int2(m01[u].z, m01[u].w), a4[u].y, b4[u].y, hasF, hasM, p.x, p.y, mf, mm);
             const float v2 = rows_entry(q0 + 2, n_old, make_int2(m23[u].x, m23[u].y), a4[u].z, b4[u].z, hasF, hasM, p.x, p.y, mf, mm);
@@ -317,7 +328,7 @@ sparse_row_fused_kernel(const float *__restrict__ M, long long ld, const int2 *_
         if (hasF && hasM && (p.x == p.y || key_found(mf, mm))) cf += static_cast<double>(half32(rowF[p.y]));
         orow[a] = static_cast<float>(cf);
     }
-    newnew_partners(static_cast<const float *>(srow), a, n_old, n_new, mi, par, meta_new, orow, so);
+    newnew_partners<kRowThreads>(static_cast<const float *>(srow), a, n_old, n_new, mi, par, meta_new, orow, so);
 }
 
 // next[c][r] = next[r][c] for the new rows r >= n_surv and the columns c < n_surv (survivors x new) or c > r
@@ -696,9 +707,9 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
             const int2 *d_meta_new = reinterpret_cast<const int2 *>(d_blob + w.o_meta_new), *d_meta_old = reinterpret_cast<const int2 *>(d_blob + w.o_meta_old);
             const bool fused = !no_fused && w.n_new > 0 && w.n_old <= 36864;
             if (fused) {   // a new row end to end per workgroup (T stays in LDS) + survivors x survivors: ONE launch
-                const long long cb = w.n_surv > 0 ? static_cast<long long>(w.n_surv) * ((w.n_surv + 2047) / 2048) : 0;
+                const long long cb = w.n_surv > 0 ? static_cast<long long>(w.n_surv) * ((w.n_surv + 8 * kRowThreads - 1) / (8 * kRowThreads)) : 0;
                 const size_t lds = std::max<size_t>(16, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
-                hipLaunchKernelGGL(sparse_row_fused_kernel, dim3(static_cast<unsigned>(w.n_new + cb)), dim3(256), lds, st, dM[cur], ld_cur, d_meta_old, w.n_old,
+                hipLaunchKernelGGL(sparse_row_fused_kernel, dim3(static_cast<unsigned>(w.n_new + cb)), dim3(kRowThreads), lds, st, dM[cur], ld_cur, d_meta_old, w.n_old,
                                    d_par, d_meta_new, w.n_new, d_newpos, dM[cur ^ 1], ld_next, w.n_surv, so, d_keep);
                 SP_GO(hipGetLastError());
             } else {   // the new rows against the old members + survivors x survivors: ONE launch (both only read the old matrix)
