@@ -174,8 +174,19 @@ def genealogy(source, sort=True):
 
 def pro(pedigree):
     """gen.pro: IDs of individuals without children, ascending (src/identify.jl:35-39)."""
-    parents = np.union1d(pedigree.father, pedigree.mother)
-    return np.sort(pedigree.ind[~np.isin(pedigree.ind, parents)])
+    ind, fa, mo = pedigree.ind, pedigree.father, pedigree.mother
+    if len(ind) == 0:
+        return ind.copy()
+    lo, hi = int(ind.min()), int(ind.max())
+    if lo > 0 and hi < 64 * len(ind) + (1 << 20) and int(min(fa.min(), mo.min())) >= 0 and int(max(fa.max(), mo.max())) <= hi:
+        # IDs in a moderate range (genea140: 41,523 IDs up to 900,506): one flag byte per ID value instead of two sorts
+        # (3-5 ms of a 12 ms gen.phi(genea140) call)
+        is_parent = np.zeros(hi + 1, dtype=bool)
+        is_parent[fa] = True
+        is_parent[mo] = True                                 # (ID 0 = unknown parent: flagged, never looked up since lo > 0)
+        return np.sort(ind[~is_parent[ind]])
+    parents = np.union1d(fa, mo)
+    return np.sort(ind[~np.isin(ind, parents)])
 
 
 def founder(pedigree):

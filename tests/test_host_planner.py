@@ -56,6 +56,23 @@ def _check_levels(gen, oracle, ind, fa, mo, sex, pro):
     pl.close()
 
 
+def test_pro_by_flag_table_and_by_sets_agree(gen):
+    """gen.pro (src/identify.jl:35-39: IDs without children, ascending) takes a flag table when the IDs lie in a moderate range and the
+    two-sort set form otherwise: both against the definition, on dense IDs, on IDs spread out beyond the table's range, and on an
+    empty pedigree's slice."""
+    from genlib_jl_amd import synth
+    def by_definition(ped):
+        parents = set(ped.father.tolist()) | set(ped.mother.tolist())
+        return np.array(sorted(x for x in ped.ind.tolist() if x not in parents), dtype=np.int64)
+    for seed in range(3):
+        ind, fa, mo, sex, _ = synth.random_mating(2500, 150, 7, seed=seed, skip_permille=100)
+        for mul in (1, 37, 1_000_003):                                       # 1_000_003: far beyond 64 IDs' worth of table per individual
+            ped = gen.genealogy({"ind": ind * mul, "father": fa * mul, "mother": mo * mul, "sex": sex})
+            assert np.array_equal(gen.pro(ped), by_definition(ped)), (seed, mul)
+    ped = gen.genealogy(gen.genea140)
+    assert np.array_equal(gen.pro(ped), by_definition(ped)) and len(gen.pro(ped)) == 140
+
+
 def test_levels_match_oracle_bundled(gen, oracle):
     for name in ["geneaJi.csv", "genea140.csv"]:
         ind, fa, mo, sex = oracle.read_tsv(os.path.join(DATA, name))
