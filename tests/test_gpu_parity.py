@@ -1338,6 +1338,19 @@ def test_sparse_phi_unsorted_ranks(gen, oracle, capfd):
         del os.environ["GENPHI_SPARSE_STALE_CAP"], os.environ["GENPHI_TRACE"]
     assert capfd.readouterr().err.count("sweep done") == 2                  # the list overflowed, the sweep ran twice
     assert K1.info() == K0.info() and all(np.array_equal(x, y) for x, y in zip(K1.entries(), K0.entries()))
+    # the other form of a wave: rows + new x new as two kernels with T in HBM (round 3; the default builds a new row end to end in LDS)
+    for knob, val in (("GENPHI_SPARSE_NO_FUSED", "1"),):
+        os.environ[knob] = val
+        try:
+            K2, _ = _sparse_check(gen, oracle, i2, f2, m2, s2, p, sort=False)
+            assert K2.info() == K0.info() and all(np.array_equal(x, y) for x, y in zip(K2.entries(), K0.entries())), (knob, val)
+            one = synth.random_mating(900, 80, 7, skip_permille=50, seed=3)
+            mo1 = one[2].copy(); mo1[::13] = 0                              # one-parent individuals
+            _sparse_check(gen, oracle, one[0], one[1], mo1, one[3], one[4])
+            g = oracle.read_tsv(gen.genea140)
+            _sparse_check(gen, oracle, *g, pro=gen.pro(gen.genealogy(gen.genea140))[:25])
+        finally:
+            del os.environ[knob]
     for args in [(300, 30, 5), (4000, 300, 9), (600, 60, 6), (4000, 300, 9)]:
         q = synth.random_mating(*args, seed=21)
         held = [_sparse_check(gen, oracle, *q[:4], q[4], sort=True)[0] for _ in range(2)]      # two results alive at once: separate host blocks
