@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
-    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
+    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_schedule", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
     "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_step_ms", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
     "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_pack_on", "genphi_panel_compute_on", "genphi_panel_sync",
     "genphi_panel_result_to_host",
@@ -130,6 +130,8 @@ def lib():
         L.genphi_sparse_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), _I64P, _F32P,
                                           C.POINTER(C.c_double), C.c_int32]
         L.genphi_sparse_stats.restype = C.c_int
+        L.genphi_sparse_schedule.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.c_int64, _I64P, _I64P, C.POINTER(C.c_int32), _I64P]
+        L.genphi_sparse_schedule.restype = C.c_int
         L.genphi_sparse_get.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, C.POINTER(C.c_double)]
         L.genphi_sparse_get.restype = C.c_int
         L.genphi_sparse_entries.argtypes = [C.c_void_p, C.c_int64, _I64P, _I64P, _F32P]
@@ -427,6 +429,23 @@ def phi_pairs(ind, father, mother, id_i, id_j, device=None):
     if rc:
         _raise(rc)
     return out
+
+
+def sparse_schedule(ind, father, mother, pro_ids):
+    """Host only: (order IDs, retire_at, wave) of the sweep gen.sparse_phi would run (genphi_sparse_schedule): the order in which
+    individuals leave the reference's queue, the processing index at which each is dropped from the live set (-1: a proband), its wave."""
+    L = lib()
+    ind, father, mother, pro_ids = _i64(ind), _i64(father), _i64(mother), _i64(pro_ids)
+    cap = len(ind)
+    order, retire, wave = np.zeros(max(cap, 1), np.int64), np.zeros(max(cap, 1), np.int64), np.zeros(max(cap, 1), np.int32)
+    n = C.c_int64()
+    rc = L.genphi_sparse_schedule(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P), len(pro_ids),
+                                  pro_ids.ctypes.data_as(_I64P), cap, order.ctypes.data_as(_I64P), retire.ctypes.data_as(_I64P),
+                                  wave.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n))
+    if rc:
+        _raise(rc)
+    n = n.value
+    return order[:n].copy(), retire[:n].copy(), wave[:n].copy()
 
 
 class KinshipMatrix:

@@ -447,8 +447,16 @@ struct genphi_sparse {
 
 extern "C" {
 
-int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pro,
-                      const int64_t *pro_ids, int32_t device, genphi_sparse **out)
+// The host's schedule of a sweep, for tests that need no GPU (genphi_sparse_schedule): per processed individual, in processing order,
+// its ID, the processing index at which it leaves the live set (-1: a proband, never) and its wave.
+struct ScheduleOut {
+    int64_t cap = 0, n = 0;
+    int64_t *ids = nullptr, *retire_at = nullptr;
+    int32_t *wave = nullptr;
+};
+
+static int sparse_impl(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pro,
+                       const int64_t *pro_ids, int32_t device, genphi_sparse **out, ScheduleOut *sched)
 {
     if (!out) return genphi_set_error(GENPHI_ERR_ARG, "genphi_sparse_phi: out is NULL");
     *out = nullptr;
@@ -511,7 +519,7 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     for (int64_t x = 0; x < n_ind; ++x) if (keep[x]) { iso_of[x] = static_cast<int>(orig.size()); orig.push_back(static_cast<int>(x)); }
     const int m = static_cast<int>(orig.size());                 // rank of pruned index u is u + 1
     R->n_pro = static_cast<int64_t>(R->ids.size());
-    if (m == 0) { *out = R; return GENPHI_OK; }
+    if (m == 0) { if (sched) { sched->n = 0; delete R; return GENPHI_OK; } *out = R; return GENPHI_OK; }
     if (m >= (1 << 30)) return bail(GENPHI_ERR_ARG, "genphi_sparse_phi: more than 2^30 individuals");
     std::vector<int> pf(m), pm(m), depth(m), nchild(m, 0);
     std::vector<char> pro_flag(m);
@@ -626,6 +634,20 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     for (double x : R->wave_bytes) R->algorithmic_bytes += x;
 
     mark("waves, blob image");
+    if (sched) {                                                  // the schedule only: no device work
+        sched->n = m;
+        int64_t k = 0;
+        for (size_t wi = 0; wi < waves.size(); ++wi)
+            for (int j = 0; j < waves[wi].n_new; ++j, ++k)
+                if (k < sched->cap) {
+                    const int u = order[k];
+                    if (sched->ids) sched->ids[k] = ind[orig[u]];
+                    if (sched->retire_at) sched->retire_at[k] = retire[u] == INT32_MAX ? -1 : retire[u];
+                    if (sched->wave) sched->wave[k] = static_cast<int32_t>(wi);
+                }
+        delete R;
+        return GENPHI_OK;
+    }
     // ---- the device sweep: every launch of every wave in stream order, one synchronisation at the end ------
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -819,6 +841,28 @@ int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, 
     }
     *out = R;
     return GENPHI_OK;
+}
+
+int genphi_sparse_phi(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pro,
+                      const int64_t *pro_ids, int32_t device, genphi_sparse **out)
+{
+    return sparse_impl(n_ind, ind, father, mother, n_pro, pro_ids, device, out, nullptr);
+}
+
+/* Host only (no GPU needed): the schedule genphi_sparse_phi would follow -- the processing order of src/compute.jl:336-345 / :431-439
+ * (IDs), for each the processing index at which it is dropped from the live set (:401-430; -1 = a proband, kept), and its wave (depth).
+ * *n_out = the number of individuals processed (probands and their ancestors); at most `cap` entries are filled. */
+int genphi_sparse_schedule(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pro,
+                           const int64_t *pro_ids, int64_t cap, int64_t *order_ids, int64_t *retire_at, int32_t *wave, int64_t *n_out)
+{
+    if (!n_out) return genphi_set_error(GENPHI_ERR_ARG, "genphi_sparse_schedule: n_out is NULL");
+    *n_out = 0;
+    ScheduleOut so;
+    so.cap = cap; so.ids = order_ids; so.retire_at = retire_at; so.wave = wave;
+    genphi_sparse *unused = nullptr;
+    const int rc = sparse_impl(n_ind, ind, father, mother, n_pro, pro_ids, -1, &unused, &so);
+    if (rc == GENPHI_OK) *n_out = so.n;
+    return rc;
 }
 
 /* Measurement of the sweep that built the handle: waves (depths), device time of the whole sweep and of every

@@ -236,6 +236,13 @@ int genphi_sparse_info(const genphi_sparse *h, int64_t *n_rows, int64_t *n_store
  * active matrix read once, the next one written once) and in total, the largest active set.  Any pointer may be NULL. */
 int genphi_sparse_stats(const genphi_sparse *h, int32_t *n_waves, double *sweep_ms, double *algorithmic_bytes,
                         int64_t *max_active, float *wave_ms, double *wave_bytes, int32_t cap);
+/* Host only, no GPU needed (diagnostic, no reference counterpart as a function): the schedule genphi_sparse_phi follows -- the order
+ * in which individuals leave the reference's queue (src/compute.jl:336-345 founders, :431-439 children) as IDs, for each the processing
+ * index at which it is dropped from the live set (:401-430: when its last child is processed; -1 = a proband, never dropped) and its
+ * wave (one wave per depth).  *n_out = the number of individuals processed (the probands and their ancestors); at most `cap` entries
+ * of each array that is not NULL are filled.  Errors as genphi_sparse_phi (unknown proband, parent after child, duplicate ID). */
+int genphi_sparse_schedule(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, int64_t n_pro,
+                           const int64_t *pro_ids, int64_t cap, int64_t *order_ids, int64_t *retire_at, int32_t *wave, int64_t *n_out);
 int genphi_sparse_get(const genphi_sparse *h, int64_t n, const int64_t *id1, const int64_t *id2, double *out);
 int64_t genphi_sparse_entries(const genphi_sparse *h, int64_t cap, int64_t *row_rank, int64_t *col_rank, float *val);
 void genphi_sparse_destroy(genphi_sparse *h);

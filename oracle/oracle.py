@@ -336,6 +336,8 @@ def _slib():
         L.sparse_oracle_info.restype = None
         L.sparse_oracle_order.argtypes = [C.c_void_p, _I64P, C.c_int64]
         L.sparse_oracle_order.restype = C.c_int64
+        L.sparse_oracle_retired.argtypes = [C.c_void_p, _I64P, _I64P, C.c_int64]
+        L.sparse_oracle_retired.restype = C.c_int64
         L.sparse_oracle_entries.argtypes = [C.c_void_p, _I64P, _I64P, _F32P, C.c_int64]
         L.sparse_oracle_entries.restype = C.c_int64
         _SLIB = L
@@ -394,6 +396,13 @@ class SparsePhi:
         buf = np.zeros(cap, dtype=np.int64)
         n = _slib().sparse_oracle_order(self._h, _p(buf), cap)
         return buf[:n].copy()
+
+    def retired(self):
+        """{ID: 0-based processing index at which the reference drops it from the live set} (src/compute.jl:401-430)."""
+        cap = 1 << 22
+        ids, at = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+        n = _slib().sparse_oracle_retired(self._h, _p(ids), _p(at), cap)
+        return dict(zip(ids[:n].tolist(), at[:n].tolist()))
 
     def entries(self):
         cap = _slib().sparse_oracle_entries(self._h, None, None, None, 0)

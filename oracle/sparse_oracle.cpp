@@ -44,6 +44,7 @@ struct Sparse {
     std::unordered_map<int, std::unordered_map<int, float>> dict;   /* Dict{Int32, Dict{Int32, Float32}} keyed by rank */
     std::unordered_map<int64_t, int> id_to_rank;                    /* probands only */
     std::vector<int64_t> order_ids;                                 /* processing order (IDs), for tests of the product's schedule */
+    std::vector<int64_t> retired_ids, retired_at;                   /* who was dropped (:401-430), and at which processing index (0-based) */
 };
 
 }  // namespace
@@ -159,6 +160,8 @@ void *sparse_oracle_create(int64_t n, const int64_t *ind, const int64_t *father,
             if (P.is_proband) continue;
             P.children_to_process -= 1;
             if (P.children_to_process == 0) {
+                S->retired_ids.push_back(P.ID);
+                S->retired_at.push_back(static_cast<int64_t>(S->order_ids.size()) - 1);
                 ranks_to_visit.erase(prank);
                 phi.erase(prank);
                 for (int rank_j : ranks_to_visit)
@@ -213,6 +216,15 @@ void sparse_oracle_info(void *h, int64_t *n_rows, int64_t *n_stored, double *sum
 }
 
 /* processing order (IDs in the order they left the queue) */
+/* the individuals dropped from the live set (:401-430) and the 0-based processing index of the child that dropped each */
+int64_t sparse_oracle_retired(void *h, int64_t *ids, int64_t *at, int64_t cap)
+{
+    Sparse *S = static_cast<Sparse *>(h);
+    const int64_t n = static_cast<int64_t>(S->retired_ids.size());
+    for (int64_t k = 0; k < n && k < cap; ++k) { ids[k] = S->retired_ids[k]; at[k] = S->retired_at[k]; }
+    return n;
+}
+
 int64_t sparse_oracle_order(void *h, int64_t *out, int64_t cap)
 {
     Sparse *S = static_cast<Sparse *>(h);
