@@ -496,7 +496,8 @@ static int sparse_impl(int64_t n_ind, const int64_t *ind, const int64_t *father,
     {
         int64_t lo = INT64_MAX, hi = INT64_MIN;
         for (int64_t i = 0; i < n_ind; ++i) { lo = std::min(lo, ind[i]); hi = std::max(hi, ind[i]); }
-        if (n_ind > 0 && lo >= 0 && hi < 8 * n_ind + 1024) { at.table.assign(static_cast<size_t>(hi) + 1, -1); at.direct = true; }
+        // (genea140: 41,523 IDs up to 900,506 -- a 3.6 MB table filled in 0.2 ms against 1.4 ms of hashing)
+        if (n_ind > 0 && lo >= 0 && hi < 64 * n_ind + (1 << 20)) { at.table.assign(static_cast<size_t>(hi) + 1, -1); at.direct = true; }
         else at.map.reserve(static_cast<size_t>(n_ind) * 2);
     }
     std::vector<int> fa(n_ind, -1), mo(n_ind, -1);
