@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
-    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_schedule", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
+    "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_schedule", "genphi_genealogy_order", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
     "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_step_ms", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
     "genphi_panel_device_bytes", "genphi_panel_begin", "genphi_panel_pack", "genphi_panel_compute", "genphi_panel_pack_on", "genphi_panel_compute_on", "genphi_panel_sync",
     "genphi_panel_result_to_host",
@@ -117,6 +117,9 @@ def lib():
         L.genphi_genealogy_read.argtypes = [C.c_char_p, C.c_int32, _I64P, C.POINTER(_I64P), C.POINTER(_I64P),
                                             C.POINTER(_I64P), C.POINTER(_I64P)]
         L.genphi_genealogy_read.restype = C.c_int
+        L.genphi_genealogy_order.argtypes = [C.c_int64, _I64P, _I64P, _I64P, _I64P, C.c_int32, _I64P, C.POINTER(_I64P), C.POINTER(_I64P),
+                                             C.POINTER(_I64P), C.POINTER(_I64P)]
+        L.genphi_genealogy_order.restype = C.c_int
         L.genphi_free.argtypes = [C.c_void_p]
         L.genphi_free.restype = None
         L.genphi_plan_release_device.argtypes = [C.c_void_p]
@@ -201,6 +204,27 @@ def genealogy_read(path, sort=True):
     n = C.c_int64()
     ptrs = [_I64P() for _ in range(4)]
     rc = L.genphi_genealogy_read(os.fsencode(path), 1 if sort else 0, C.byref(n), *[C.byref(p) for p in ptrs])
+    if rc:
+        _raise(rc)
+    try:
+        out = tuple(np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64) for p in ptrs)
+    finally:
+        for p in ptrs:
+            L.genphi_free(p)
+    return out
+
+
+def genealogy_order(ind, father, mother, sex, sort=True):
+    """(ind, father, mother, sex) int64 arrays in rank order from a table in memory (genphi_genealogy_order): the checks and the
+    stable depth sort of gen.genealogy(dataframe; sort), natively."""
+    L = lib()
+    ind, father, mother, sex = _i64(ind), _i64(father), _i64(mother), _i64(sex)
+    if not (len(ind) == len(father) == len(mother) == len(sex)):
+        raise ValueError("ind, father, mother, sex must have the same length")
+    n = C.c_int64()
+    ptrs = [_I64P() for _ in range(4)]
+    rc = L.genphi_genealogy_order(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P),
+                                  sex.ctypes.data_as(_I64P), 1 if sort else 0, C.byref(n), *[C.byref(p) for p in ptrs])
     if rc:
         _raise(rc)
     try:

@@ -190,6 +190,13 @@ int genphi_compute_f32(genphi_plan *plan, float *out, const genphi_opts *opts,
  * parent -> GENPHI_ERR_UNKNOWN_ID; sort == 0 and a parent after its child -> GENPHI_ERR_ORDER. */
 int genphi_genealogy_read(const char *path, int32_t sort, int64_t *n, int64_t **ind, int64_t **father,
                           int64_t **mother, int64_t **sex_out);
+/* The same for a table already in memory (gen.genealogy(dataframe; sort), src/create.jl:131-146, ordered by :196-254): ind / father /
+ * mother (/ sex, may be NULL) in file order -> malloc'ed arrays in rank order (release with genphi_free).  Errors as
+ * genphi_genealogy_read: GENPHI_ERR_DUPLICATE_ID, GENPHI_ERR_UNKNOWN_ID (a parent that is not an individual: KeyError in the reference),
+ * GENPHI_ERR_ARG (a cycle), and with sort = 0 GENPHI_ERR_ORDER (a parent listed after its child: KeyError, src/create.jl:240-241). */
+int genphi_genealogy_order(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother, const int64_t *sex,
+                           int32_t sort, int64_t *n_out, int64_t **ind_out, int64_t **father_out, int64_t **mother_out,
+                           int64_t **sex_out);
 void genphi_free(void *ptr);
 
 /* gen.branching(pedigree; pro, ancestors) (src/extract.jl:65-186), the pruning step before the

@@ -56,6 +56,39 @@ def _check_levels(gen, oracle, ind, fa, mo, sex, pro):
     pl.close()
 
 
+def test_genealogy_from_a_table_in_memory(gen, oracle):
+    """gen.genealogy(dataframe; sort) (src/create.jl:131-146 + the ordering of :196-254) through genphi_genealogy_order: the rank order
+    of the oracle for shuffled files (stable on depth ties), IDs far apart (hash map instead of the direct table), a pandas DataFrame,
+    sort=false, and the reference's errors."""
+    import pandas as pd
+    from genlib_jl_amd import synth
+    for seed in range(3):
+        ind, fa, mo, sex, _ = synth.random_mating(3000, 200, 9, seed=seed, skip_permille=150)
+        perm = np.random.default_rng(seed).permutation(len(ind))                      # children before their parents in the file
+        for mul in (1, 1_000_003):
+            cols = [a[perm] * (mul if k < 3 else 1) for k, a in enumerate((ind, fa, mo, sex))]
+            ped = gen.genealogy(dict(zip(("ind", "father", "mother", "sex"), cols)))
+            oped = oracle.Pedigree(cols[0], cols[1], cols[2])
+            assert np.array_equal(ped.ind, oped.ind) and np.array_equal(ped.father, oped.father) and np.array_equal(ped.mother, oped.mother)
+            assert np.array_equal(ped.sex, cols[3][np.argsort(cols[0])][np.searchsorted(np.sort(cols[0]), ped.ind)])
+        i2, f2, m2, s2 = synth.parents_first_shuffle(ind, fa, mo, sex, seed=seed)
+        ped = gen.genealogy({"ind": i2, "father": f2, "mother": m2, "sex": s2}, sort=False)
+        assert np.array_equal(ped.ind, i2) and np.array_equal(ped.father, f2)          # file order kept
+    df = pd.DataFrame({"ind": [3, 1, 2], "father": [1, 0, 0], "mother": [2, 0, 0], "sex": [1, 1, 2]})
+    assert gen.genealogy(df).ind.tolist() == [1, 2, 3]
+    assert len(gen.genealogy({"ind": [], "father": [], "mother": [], "sex": []}).ind) == 0
+    with pytest.raises(ValueError):                                                  # duplicate ID (refused, not last-wins)
+        gen.genealogy({"ind": [1, 1], "father": [0, 0], "mother": [0, 0], "sex": [1, 1]})
+    with pytest.raises(KeyError):                                                    # a parent that is not an individual
+        gen.genealogy({"ind": [1, 2], "father": [0, 7], "mother": [0, 0], "sex": [1, 1]})
+    with pytest.raises(ValueError):                                                  # a cycle
+        gen.genealogy({"ind": [1, 2], "father": [2, 1], "mother": [0, 0], "sex": [1, 1]})
+    with pytest.raises(KeyError):                                                    # sort=false: parent after child (src/create.jl:240-241)
+        gen.genealogy({"ind": [2, 1], "father": [1, 0], "mother": [0, 0], "sex": [1, 1]}, sort=False)
+    with pytest.raises(ValueError):
+        gen.genealogy({"ind": [1, 2], "father": [0], "mother": [0, 0], "sex": [1, 1]})
+
+
 def test_pro_by_flag_table_and_by_sets_agree(gen):
     """gen.pro (src/identify.jl:35-39: IDs without children, ascending) takes a flag table when the IDs lie in a moderate range and the
     two-sort set form otherwise: both against the definition, on dense IDs, on IDs spread out beyond the table's range, and on an
