@@ -22,6 +22,7 @@ GENPHI_ERR_ARG = 6
 GENPHI_MAX_STAT_LEVELS = 1024
 GENPHI_FLAG_NO_GRAPH = 1
 GENPHI_FLAG_STORAGE_F64 = 2
+GENPHI_FLAG_NO_SPARSE = 4
 
 _I64P = C.POINTER(C.c_int64)
 _F32P = C.POINTER(C.c_float)
@@ -44,7 +45,7 @@ class GenphiStats(C.Structure):
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
-    "genphi_plan_algorithmic_bytes", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
+    "genphi_plan_algorithmic_bytes", "genphi_plan_sparse_levels", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
@@ -93,6 +94,8 @@ def lib():
         L.genphi_plan_step_walk.restype = C.c_int
         L.genphi_plan_set_step_hook.argtypes = [C.c_void_p, STEP_FN, C.c_void_p]
         L.genphi_plan_set_step_hook.restype = C.c_int
+        L.genphi_plan_sparse_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _I64P, C.c_int32]
+        L.genphi_plan_sparse_levels.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
         L.genphi_compute_device.argtypes = [C.c_void_p, C.POINTER(GenphiOpts), C.POINTER(GenphiStats)]
@@ -355,19 +358,28 @@ class PhiPlan:
         n = len(self.levels()[0]) - 1
         return [int(lib().genphi_plan_step_mode(self._h, k)) for k in range(max(n, 0))]
 
-    def _opts(self, device, kernel, rows, timing, storage64=False, no_graph=False):
+    def sparse_levels(self):
+        """(k, nnz): the last cut the Float32 sweep keeps as lists of its non-zero entries (-1: every level is a dense matrix, or no
+        sweep has run yet) and the non-zero entries counted per cut (-1 = not counted), genphi_plan_sparse_levels."""
+        k = C.c_int32(-1)
+        buf = (C.c_int64 * 16)()
+        m = lib().genphi_plan_sparse_levels(self._h, C.byref(k), buf, 16)
+        return int(k.value), [int(buf[c]) for c in range(m)]
+
+    def _opts(self, device, kernel, rows, timing, storage64=False, no_graph=False, no_sparse=False):
         o = GenphiOpts()
         o.device = -1 if device is None else int(device)
         o.kernel = int(kernel)
         o.row_begin, o.row_end = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
         o.timing = 1 if timing else 0
-        o.flags = (GENPHI_FLAG_STORAGE_F64 if storage64 else 0) | (GENPHI_FLAG_NO_GRAPH if no_graph else 0)
+        o.flags = (GENPHI_FLAG_STORAGE_F64 if storage64 else 0) | (GENPHI_FLAG_NO_GRAPH if no_graph else 0) | (GENPHI_FLAG_NO_SPARSE if no_sparse else 0)
         return o
 
-    def compute_device(self, device=None, kernel=0, rows=None, timing=False, storage64=False, no_graph=False):
+    def compute_device(self, device=None, kernel=0, rows=None, timing=False, storage64=False, no_graph=False, no_sparse=False):
         """Run all level steps on the GPU; the result stays resident in HBM.  storage64: Float64
-        level matrices (the values of the reference's Float64 pairwise recursion)."""
-        o = self._opts(device, kernel, rows, timing, storage64, no_graph)
+        level matrices (the values of the reference's Float64 pairwise recursion).  no_sparse: every level as a dense matrix
+        (GENPHI_FLAG_NO_SPARSE; same values)."""
+        o = self._opts(device, kernel, rows, timing, storage64, no_graph, no_sparse)
         st = GenphiStats()
         rc = lib().genphi_compute_device(self._h, C.byref(o), C.byref(st))
         if rc:
@@ -435,8 +447,8 @@ class PhiPlan:
             raise ValueError("phi_mean needs all rows resident; combine result_sums() of the shards instead")
         return np.float32((a - d) / (n * n - n))
 
-    def compute(self, device=None, kernel=0, rows=None, timing=False):
-        self.compute_device(device=device, kernel=kernel, rows=rows, timing=timing)
+    def compute(self, device=None, kernel=0, rows=None, timing=False, no_sparse=False):
+        self.compute_device(device=device, kernel=kernel, rows=rows, timing=timing, no_sparse=no_sparse)
         return self.result_to_host()
 
 

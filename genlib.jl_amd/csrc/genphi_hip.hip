@@ -54,6 +54,7 @@
 #include "../../include/genphi.h"
 #include "panel_launch.h"
 #include "planner.h"
+#include "sparse_levels.h"
 
 using genphi::LevelStep;
 using genphi::Plan;
@@ -2020,6 +2021,11 @@ struct Tuning {
     int d2h_sym = -1;              // GENPHI_D2H_SYM          opt-in: 1 = a full result crosses the link as upper-triangle tiles + a host mirror pass (default: every entry is copied)
     int d2h_tile_rows = 0, d2h_tile_cols = 0;   // GENPHI_D2H_TILE "RxC"  test + tuning: tile of the symmetric copy (default 256 x 8192)
     int fail_alloc_at = 0;         // GENPHI_TEST_FAIL_ALLOC  test: the k-th device allocation of an upload fails (error-path test)
+    int sparse_k = -2;             // GENPHI_SPARSE_K         A/B + test: last cut kept as row lists (sparse_levels.h): -1 = none (every level dense), k >= 0 = cuts 0..k
+                                   //                         whatever their density (clamped to the eligible steps); default: by the calibration run's counts
+    int sparse_permille = -1;      // GENPHI_SPARSE_PERMILLE  tuning: a cut stays sparse while at most this share (1/1000) of its entries is non-zero
+    int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
+    int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
 };
 
 static Tuning tuning_from_env()
@@ -2073,6 +2079,10 @@ static Tuning tuning_from_env()
         if (std::sscanf(e, "%dx%d", &r, &c) == 2 && r >= 1 && c >= 1) { t.d2h_tile_rows = r; t.d2h_tile_cols = c; }
     }
     t.fail_alloc_at = geti("GENPHI_TEST_FAIL_ALLOC", 0);
+    t.sparse_k = geti("GENPHI_SPARSE_K", -2);
+    t.sparse_permille = geti("GENPHI_SPARSE_PERMILLE", -1);
+    t.sparse_min_cut = geti("GENPHI_SPARSE_MIN_CUT", -1);
+    t.sparse_chunk = geti("GENPHI_SPARSE_CHUNK", 0);
     return t;
 }
 
@@ -2205,6 +2215,9 @@ struct genphi_plan {
     bool res_f64 = false;                        // the resident result is the Float64 one
     size_t result_floats = 0, final_tmp_floats = 0;
     int64_t res_ld = 0, res_row_begin = 0, res_n_rows = 0;
+    // zero-aware leading levels (sparse_levels.h): created and calibrated by the first product sweep of the plan
+    genphi::SparseLevels *sparse = nullptr;
+    bool sparse_tried = false;
     std::vector<hipEvent_t> events;
     std::vector<void *> pin;                // pinned staging chunks of genphi_result_to_host (2 per worker)
     std::vector<hipStream_t> pin_streams;
@@ -2241,6 +2254,7 @@ static void free_device(genphi_plan *p)
     release(p->buf64[0]); release(p->buf64[1]); release(p->result64); release(p->d_perm_rows);
     p->buf64_doubles[0] = p->buf64_doubles[1] = 0; p->result64_doubles = 0; p->perm_rows_cap = 0; p->res_f64 = false;
     p->nn_steps.clear(); p->nn_dsteps.clear(); p->cert_p_words = 0;
+    genphi::sparse_levels_destroy(p->sparse); p->sparse = nullptr; p->sparse_tried = false;      // (its index arrays live inside idx_blob)
     p->d_final_perm = nullptr;                       // lived inside idx_blob
     p->d_final_slots = nullptr;
     p->dsteps.clear(); p->sh_steps.clear();
@@ -2343,6 +2357,16 @@ int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
     return GENPHI_OK;
 }
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
+int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap)
+{
+    if (k_out) *k_out = -1;
+    if (!plan || !plan->sparse) return 0;
+    if (k_out) *k_out = genphi::sparse_levels_k(plan->sparse);
+    std::vector<long long> v(std::max(cap, 0), -1);
+    const int m = genphi::sparse_levels_counts(plan->sparse, cap, v.data(), nullptr);
+    for (int c = 0; c < m && nnz; ++c) nnz[c] = v[c];
+    return m;
+}
 int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user)
 {
     if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
@@ -3353,6 +3377,32 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     if (rc) return rc;
     trace.mark("ensure_level_buffers");
     const int n_steps = L - 1;
+    // Zero-aware leading levels (sparse_levels.h): the first product sweep of a plan builds the children lists of the eligible
+    // steps and runs them once to count the non-zero entries of every cut; that fixes k, the last cut kept as row lists, for
+    // the life of the plan (values do not depend on k; GENPHI_FLAG_NO_SPARSE runs the same plan densely).
+    if (kernel == 0 && !p->sparse_tried) {
+        p->sparse_tried = true;
+        const int S = p->tun.sparse_k == -1 ? 0 : genphi::sparse_eligible_steps(pl);
+        if (S >= 2) {
+            std::vector<genphi::SparseStepDev> dev(S);
+            for (int s = 0; s < S; ++s) dev[s] = genphi::SparseStepDev{p->dsteps[s].srcA, p->dsteps[s].srcB, p->dsteps[s].ord};
+            genphi::SparseTuning stn;
+            stn.force_k = p->tun.sparse_k;
+            if (p->tun.sparse_permille > 0) stn.max_permille = p->tun.sparse_permille;
+            if (p->tun.sparse_min_cut >= 0) stn.min_cut = p->tun.sparse_min_cut;
+            if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
+            std::string serr;
+            p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
+            if (p->sparse) {
+                rc = genphi::sparse_levels_calibrate(p->sparse, p->stream, serr);
+                if (rc) return fail(rc, "sparse levels: " + serr);
+            } else {
+                (void)hipGetLastError();          // (no memory for the row lists: the sweep stays dense)
+            }
+        }
+        trace.mark("sparse levels: lists + calibration");
+    }
+    const int sparse_k = (kernel == 0 && p->sparse && !(opts && (opts->flags & GENPHI_FLAG_NO_SPARSE))) ? genphi::sparse_levels_k(p->sparse) : -1;
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
         while (static_cast<int>(p->events.size()) < n_steps + 3) {
@@ -3518,7 +3568,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             // (materialised only for kernels that read it: level_identity_kernel and the fused
             //  small-level run start from the indices)
             const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
-            if (kernel == 1 || !identity_source(0, p->tun)) {
+            if (kernel == 1 || (!identity_source(0, p->tun) && sparse_k < 0)) {
                 HIP_TRY(hipMemsetAsync(p->buf[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(float), p->stream));
                 hipLaunchKernelGGL(half_identity_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0,
                                    p->stream, p->buf[0], ld0, static_cast<int>(n0), static_cast<const int *>(nullptr),
@@ -3530,6 +3580,16 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 const float *psi = p->buf[bid[s]];
                 const bool last = s == n_steps - 1;
                 if (p->step_hook) p->step_hook(s, n_steps, p->step_hook_user);
+                if (s <= sparse_k) {
+                    // cuts 0..sparse_k are row lists: a list step, or (s == sparse_k) the step that writes cut s+1 as a dense matrix
+                    std::string serr;
+                    rc = s < sparse_k ? genphi::sparse_levels_enqueue_step(p->sparse, s, p->stream, serr)
+                                      : genphi::sparse_levels_enqueue_dense(p->sparse, p->buf[bid[s + 1]], st.ld, st.width, p->stream, serr);
+                    if (rc == GENPHI_OK && s == sparse_k) rc = genphi::sparse_levels_enqueue_flags(p->sparse, p->stream, serr);
+                    if (rc) return fail(rc, "sparse levels: " + serr);
+                    if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
+                    continue;
+                }
                 // a run of >= 2 small intermediate steps goes through ONE launch (levels_small_kernel)
                 if (kernel == 0 && !small_off) {
                     int e = s;
@@ -3620,7 +3680,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     // opts kernels into their LDS), the sweep is captured into a hipGraph and replayed.
     // Timing runs stay eager (they need events between the launches).
     const bool graphs_off = p->tun.no_graph;
-    const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), need_perm ? 1 : 0, p->alloc_gen};
+    const long long key[5] = {kernel, static_cast<long long>(r0), static_cast<long long>(r1), (need_perm ? 1 : 0) | (sparse_k >= 0 ? 2 : 0), p->alloc_gen};
     const bool same_as_eager = p->eager_valid && std::memcmp(key, p->eager_key, sizeof(key)) == 0;
     const bool use_graph = !timing && !graphs_off && !(opts && (opts->flags & GENPHI_FLAG_NO_GRAPH)) && same_as_eager && n_steps >= 8 && !p->step_hook;
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
@@ -3658,6 +3718,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     trace.mark("sweep enqueued");
     HIP_TRY(hipStreamSynchronize(p->stream));
     trace.mark("sweep done");
+    if (sparse_k >= 0 && !genphi::sparse_levels_flags_ok(p->sparse))
+        return fail(GENPHI_ERR_DEVICE, "sparse levels: a row list did not have the length the plan recorded (internal error)");
     if (timing) {
         const int ne = std::max(n_steps, 1);
         float ms = 0.f;

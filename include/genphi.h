@@ -55,6 +55,10 @@ typedef struct genphi_opts {
                                         recursion (src/compute.jl:66-95) instead of gen.phi's Float32-per-level
                                         matrices; for gen.f / pairwise queries (per-entry kernel, small sets)   */
 
+#define GENPHI_FLAG_NO_SPARSE     4   /* every level as a dense matrix: the leading cuts, whose matrices are almost empty, are
+                                        otherwise kept as lists of their non-zero entries (the idea of the reference's second
+                                        algorithm, src/compute.jl:391-394; genphi_plan_sparse_levels).  Same values either way. */
+
 #define GENPHI_MAX_STAT_LEVELS 1024
 typedef struct genphi_stats {
     int32_t n_steps;                 /* level steps run (L-1)                               */
@@ -124,6 +128,14 @@ int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows
  * The hook must not call back into the library with the same plan.                                                              */
 typedef void (*genphi_step_fn)(int32_t step, int32_t n_steps, void *user);
 int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user);
+
+/* Diagnostic: the zero-aware leading levels of the plan's Float32 sweep.  The level matrices right below the founders are almost
+ * empty (Psi = 1/2 I at the top, src/compute.jl:271-274; an entry is non-zero only where two members share an ancestor above), so
+ * the sweep keeps cuts 0..k as lists of their non-zero entries -- what the reference's sparse_phi stores, src/compute.jl:391-394 --
+ * and step k writes cut k+1 as the first dense matrix.  k is fixed by the first genphi_compute_device of the plan, which counts the
+ * non-zero entries of the leading cuts on the GPU.  *k_out = k (-1: every level is dense, or no sweep has run yet); nnz[c] = non-zero
+ * entries of cut c for the cuts that were counted (-1 = not counted), at most `cap` entries; returns how many were filled.          */
+int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap);
 
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);

@@ -1483,3 +1483,93 @@ def test_failed_upload_leaves_a_clean_plan(gen, oracle, monkeypatch):
         _assert_equal(pp.result_to_host(), want)
         pp.close()
     monkeypatch.delenv("GENPHI_TEST_FAIL_ALLOC", raising=False)
+
+
+def _random_mixed_pedigree(rng, n_gen, per_gen, p_one_parent=0.1, p_skip=0.2, p_founder=0.05):
+    """Generations with parents from g-1 or g-2, one-parent members and late founders."""
+    ind, fa, mo, gens, nxt = [], [], [], [], 1
+    for g in range(n_gen):
+        ids = list(range(nxt, nxt + per_gen)); nxt += per_gen
+        for x in ids:
+            f = m = 0
+            if g > 0 and rng.random() >= p_founder:
+                gf = g - 2 if (g >= 2 and rng.random() < p_skip) else g - 1
+                gm = g - 2 if (g >= 2 and rng.random() < p_skip) else g - 1
+                f = int(rng.choice(gens[gf][0::2])); m = int(rng.choice(gens[gm][1::2]))
+                u = rng.random()
+                if u < p_one_parent / 2:
+                    f = 0
+                elif u < p_one_parent:
+                    m = 0
+            ind.append(x); fa.append(f); mo.append(m)
+        gens.append(ids)
+    a = lambda v: np.asarray(v, dtype=np.int64)
+    return a(ind), a(fa), a(mo), a([1 + (k % 2) for k in range(len(ind))]), a(gens[-1])
+
+
+def test_sparse_leading_levels(gen, oracle, monkeypatch):
+    """The leading cuts of a sweep are kept as lists of their non-zero entries (csrc/sparse_levels.hip; the reference's sparse_phi
+    stores only `coefficient > 0.` for the same reason, src/compute.jl:391-394): bit-equal to the oracle and to the same plan run
+    densely (GENPHI_FLAG_NO_SPARSE), by calibration and with the last sparse cut forced, with row shards and graph replay."""
+    from genlib_jl_amd import synth
+    for name in ("GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_CHUNK"):
+        monkeypatch.delenv(name, raising=False)
+    gold = np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy"))
+    ped = gen.genealogy(gen.genea140)
+    # default settings: genea140's wide cuts are 0.2-1.2 % non-zero, so most of its levels run on lists
+    pl = gen.plan(ped)
+    phi = pl.compute()
+    k, nnz = pl.sparse_levels()
+    sizes = pl.levels()[0]
+    assert k >= 6, (k, nnz)
+    assert nnz[0] == sizes[0] and all(0 < nnz[c] <= 0.2 * sizes[c] ** 2 for c in range(1, k + 1)), (nnz, sizes)
+    _assert_equal(phi, gold)
+    _assert_equal(pl.compute(no_sparse=True), gold)
+    _assert_equal(pl.compute(), gold)                               # (second sparse sweep: counters and cursors start again)
+    parts = [pl.compute(rows=(a, b)) for a, b in [(0, 70), (70, 71), (71, 140)]]
+    _assert_equal(np.concatenate(parts, axis=0), gold)
+    for _ in range(3):                                              # graph replay (17 steps)
+        pl.compute_device()
+    _assert_equal(pl.result_to_host(), gold)
+    pl.close()
+    for force in ("1", "4", "9", "11", "-1"):
+        monkeypatch.setenv("GENPHI_SPARSE_K", force)
+        pl = gen.plan(ped)
+        _assert_equal(pl.compute(), gold)
+        assert pl.sparse_levels()[0] == {"1": 1, "4": 4, "9": 9, "11": 10, "-1": -1}[force], pl.sparse_levels()      # (cut 11 is the last one exact in integer units)
+        pl.close()
+    monkeypatch.delenv("GENPHI_SPARSE_K", raising=False)
+    # small chunks of the sparse -> dense step: rows of several workgroups
+    monkeypatch.setenv("GENPHI_SPARSE_CHUNK", "1024")
+    _assert_equal(gen.phi(ped), gold)
+    monkeypatch.delenv("GENPHI_SPARSE_CHUNK", raising=False)
+    # random mating (every row of every cut new, no dragged members) and overlapping generations, by calibration
+    for args, kw in (((30000, 3000, 10), dict(skip_permille=0)), ((30000, 2000, 14), dict(skip_permille=30))):
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        ped2 = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        monkeypatch.setenv("GENPHI_STAY_NARROW", "0")              # (in-place runs end the eligible steps early)
+        pl = gen.plan(ped2, pro)
+        _assert_equal(pl.compute(), want)
+        assert pl.sparse_levels()[0] >= 2, pl.sparse_levels()
+        _assert_equal(pl.compute(no_sparse=True), want)
+        pl.close()
+        monkeypatch.delenv("GENPHI_STAY_NARROW", raising=False)
+        _assert_equal(gen.phi(ped2, pro), want)
+    # small pedigrees with every sparse cut forced: one-parent members, late founders, parents from two generations up,
+    # probands that are ancestors of probands; dense (up to 100 % non-zero) "sparse" cuts
+    monkeypatch.setenv("GENPHI_SPARSE_K", "11")
+    monkeypatch.setenv("GENPHI_SPARSE_MIN_CUT", "0")
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        ind, fa, mo, sex, last = _random_mixed_pedigree(rng, int(rng.integers(3, 16)), int(rng.integers(8, 300)))
+        pro = np.unique(np.concatenate([last, rng.choice(ind, size=min(7, len(ind)), replace=False)]))
+        ped3 = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        pl = gen.plan(ped3, pro)
+        _assert_equal(pl.compute(), want)
+        n_steps = len(pl.levels()[0]) - 1
+        assert pl.sparse_levels()[0] == min(10, n_steps - 2) or n_steps < 3, (pl.sparse_levels(), n_steps)      # (never the proband step, never beyond cut 11)
+        pl.close()
+    pedj = gen.genealogy(gen.geneaJi)
+    _assert_equal(gen.phi(pedj), np.array(GOLD["geneaJi"]["phi"], dtype=np.float32))
