@@ -2,18 +2,29 @@
 //
 // Replaces, for the cuts right below the founders, what src/compute.jl:291-301 does with a fresh dense matrix per level:
 // the same entries (src/compute.jl:105-158 evaluated pair by pair) are produced row by row from the non-zero entries of
-// the previous cut only.  Row i of cut s+1 is
-//     Psi'[i][j] = w_i w_j sum_{p in src(i)} sum_{q in src(j)} Psi[p][q]          (w = 1 dragged, 1/2 new; planner.h)
-// i.e. every non-zero (q, v) of the source rows of i contributes w_i w_j v to the columns j that have q as a source -- the
-// CHILDREN of q (q itself when it is dragged along, weight 1; its new children, weight 1/2).  The diagonal of a new member
-// is 1/2 + Psi[f][m]/2 when both parents exist, 1/2 otherwise (src/compute.jl:148-154).
+// the previous cut only.  A level step is Psi' = A Psi A^T with the diagonal rule of src/compute.jl:148-154, A's rows being a
+// unit vector (member dragged along) or (e_father + e_mother) / 2 (new member; planner.h).  It is evaluated in two halves:
 //
-// Layout in HBM.  A sparse cut is two arrays: rowd[i] = (first entry, number of entries) per member and ent[] = (column,
-// Float32 bits) pairs, the entries of a row contiguous and ascending by column.  Rows are placed by an atomic cursor, so their
-// order in ent[] varies from run to run; their contents do not.  Two arenas alternate between consecutive cuts.
+//     Y  = Psi A^T      row p of the SOURCE cut with its columns mapped to the columns of the cut being written: a non-zero
+//                       (q, v) of row p goes to every CHILD of q (q itself when it is dragged along, weight 1; its new
+//                       children, weight 1/2)
+//     Psi'[i] = w_i (Y[A_i] + Y[B_i])       A_i, B_i = the sources of member i, w_i = 1 dragged, 1/2 new
 //
-// Arithmetic: integer units of 2^-(2c+1) for cut c (exact for c <= 11, see sparse_levels.h), accumulated with LDS atomics;
-// Float32 values are rebuilt by one exact conversion.  No rank words are needed: every grouping of the reference's sum is exact.
+// and the half that needs scattered index lookups -- the children of every column of a row -- is done ONCE per row, by the
+// workgroup that has just built that row in LDS: a sparse cut is stored as its rows of Y.  The step that reads them streams
+// two contiguous lists per output row; nothing else.
+//
+// Layout in HBM.  Sparse cut c: rowd[c][p] = (first entry, entries) per member p, ent[] = (column in cut c+1, integer value)
+// pairs: the entries of row p of Y_c, unsorted, a column may occur twice (two parents of a child both related to p).  fm[c][i]
+// per member i of cut c+1 = Psi_c[A_i][B_i], the kinship of i's parents, which its diagonal needs (written by the workgroup
+// that built row A_i of Psi_c).  Two arenas alternate between consecutive cuts.  Where a row goes in the arena: the
+// calibration run of a plan places rows with an atomic cursor and records (place, length) per row; every later sweep writes
+// the row to that place -- lengths depend on the pedigree alone, and 24k same-address device-scope atomics per level cost
+// more than the level itself (measured: 0.56 ms per level of cfg4 whatever its size).
+//
+// Arithmetic: integers.  Psi_c in units of 2^-(2c+1), Y_c in units of 2^-(2c+2) (exact for c <= 11, see sparse_levels.h),
+// accumulated with LDS atomics; Float32 values are built by one exact conversion when the first dense matrix is written.  No
+// rank words are needed: every grouping of the reference's sum is exact.
 #include "sparse_levels.h"
 
 #include <algorithm>
@@ -29,43 +40,49 @@ namespace {
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 struct SpArgs {
-    const uint2 *ent_in;          // source cut: (column, Float32 bits) ...
-    const uint2 *rowd_in;         // ... and per row (first entry, entries)
-    uint2 *ent_out;               // (row-list step) entries of the cut written
-    uint2 *rowd_out;              // (row-list step) its row descriptors: written by the calibration run (rows placed by an atomic cursor),
-    int fixed;                    //   read by every later sweep (fixed != 0: the row's place and length are the plan's; a length that differs is an error)
-    const int *srcA, *srcB, *ord; // per member of the cut written: sources in the source cut (n_prev = none), rank word (< 0: new)
-    const int *ch_off;            // children of member q of the source cut: ch[ch_off[q] .. ch_off[q + 1])
-    const unsigned *ch;           // position in the cut written | 0x80000000 when the child is q itself (dragged: weight 1)
-    int n_prev, n;
-    int wp;                       // (row-list step) bitmap words in LDS: workgroup size x an odd number
-    int cap;                      // (row-list step) entries of one row the LDS holds
-    unsigned ent_cap;             // (row-list step) entries the arena written holds
-    float scale_in;               // 2^(2c+1): a value of the source cut c in integer units
-    float unit_out;               // 2^-(2c+3): one integer unit of the cut written
-    unsigned half_out;            // 1/2 in units of the cut written
-    unsigned *stat;               // (row-list step) [0] entries written so far, [1] longest row, [2] 1 = a row or the arena overflowed, 2 = a row's length changed
+    // the source cut s as rows of Y_s (columns = members of cut s+1)
+    const uint2 *ent_in;
+    const uint2 *rowd_in;
+    const unsigned *fm_in;        // per member i of cut s+1: Psi_s[A_i][B_i] in units of 2^-(2s+1)
+    const int *srcA, *srcB, *ord; // per member of cut s+1: sources in cut s (n_prev = none), rank word (< 0: new)
+    int n_prev, n;                // |cut s|, |cut s+1|
+    unsigned half_out;            // 1/2 in units of cut s+1: 2^(2s+2)
+    // row-list step: cut s+1 written as rows of Y_{s+1} (columns = members of cut s+2)
+    uint2 *ent_out;
+    uint2 *rowd_out;              // written by the calibration run, read by every later sweep (fixed != 0)
+    int fixed;
+    unsigned ent_cap;             // entries the arena written holds
+    const int *chn_off;           // children of member q of cut s+1 in cut s+2: chn[chn_off[q] .. chn_off[q + 1])
+    const unsigned *chn;          //   position in cut s+2 | 0x80000000 when the child is q itself (dragged: weight 1)
+    const int *mt_off;            // mates of member p of cut s+1: mt[mt_off[p] .. mt_off[p + 1]) = (B, i) for every new member i of
+    const uint2 *mt;              //   cut s+2 with A_i = p and a second parent B
+    unsigned *fm_out;             // per member of cut s+2
+    int wp;                       // bitmap words in LDS: workgroup size x an odd number
+    int cap;                      // entries of one row of Psi_{s+1} the LDS holds
+    unsigned *stat;               // [0] entries of Y written so far, [1] longest row of Psi, [2] 1 = a row or the arena overflowed, 2 = a row's
+                                  // length differs from the plan's, [3] non-zero entries of Psi (calibration run)
     // sparse -> dense step
     float *out;
     long long ld;
     int width, chunk_cols, n_chunks;
+    float unit_out;               // 2^-(2s+3): one integer unit of cut s+1
 };
 
-// the lists of Psi_0 = 1/2 I (src/compute.jl:271-274) and the counters of a sweep
-__global__ void __launch_bounds__(256) sparse_identity_kernel(uint2 *ent, uint2 *rowd, int n0, unsigned *stat, int n_stat)
+// Y_0 = (1/2 I) A^T: row p is the children list of p itself; fm_0[i] = Psi_0[A_i][B_i] = 1/2 only when a member's two parents are
+// the same founder; the counters of a sweep.  (src/compute.jl:271-274)
+__global__ void __launch_bounds__(256) sparse_identity_kernel(uint2 *ent, uint2 *rowd, const int *ch_off, const unsigned *ch, int n0, int n_ch,
+                                                              const int *srcA, const int *srcB, const int *ord, unsigned *fm, int n1,
+                                                              unsigned *stat, int n_stat)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n0) {
-        ent[k] = make_uint2(static_cast<unsigned>(k), __float_as_uint(0.5f));
-        rowd[k] = make_uint2(static_cast<unsigned>(k), 1u);
+    if (k < n_ch) {
+        const unsigned cw = ch[k];
+        ent[k] = make_uint2(cw & 0x7fffffffu, (cw >> 31) + 1u);
     }
-    if (k < n_stat) stat[k] = k == 0 ? static_cast<unsigned>(n0) : (k == 1 ? 1u : 0u);
+    if (k < n0) rowd[k] = make_uint2(static_cast<unsigned>(ch_off[k]), static_cast<unsigned>(ch_off[k + 1] - ch_off[k]));
+    if (k < n1) fm[k] = (ord[k] < 0 && srcA[k] == srcB[k] && srcA[k] != n0) ? 1u : 0u;
+    if (k < n_stat) stat[k] = 0u;
 }
-
-// The entries of the (<= 2) source rows of an output row as ONE index space [0, lenA + lenB), walked kBatch entries per thread at a
-// time with the loads of a batch issued together: entry -> children range -> children are three dependent round trips through
-// L2, and a row's time is the number of such chains a thread walks one after the other.
-constexpr int kBatch = 4;
 
 struct SrcRows {
     unsigned offA, lenA, offB, total;
@@ -79,39 +96,58 @@ __device__ __forceinline__ SrcRows src_rows(const SpArgs &a, int A, int B)
     return SrcRows{ra.x, ra.y, rb.x, ra.y + rb.y};
 }
 
-// f(entry from row A?, q, integer value of the entry, first child, end child) for every entry of the two source rows
+// the entries of the (<= 2) source rows of an output row as ONE index space: contiguous, coalesced 8-byte loads
 template <int NT, class F>
 __device__ __forceinline__ void for_each_entry(const SpArgs &a, const SrcRows &r, int tid, F &&f)
 {
+    constexpr int kBatch = 4;
     for (unsigned e0 = tid; e0 < r.total; e0 += kBatch * NT) {
         uint2 en[kBatch];
-        bool ok[kBatch], fromA[kBatch];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const unsigned e = e0 + b * NT;
-            ok[b] = e < r.total;
-            const unsigned ee = ok[b] ? e : r.total - 1u;
-            fromA[b] = ee < r.lenA;
-            en[b] = a.ent_in[fromA[b] ? r.offA + ee : r.offB + (ee - r.lenA)];
-        }
-        int k0[kBatch], k1[kBatch];
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            k0[b] = a.ch_off[en[b].x];
-            k1[b] = a.ch_off[en[b].x + 1u];
+            const unsigned e = min(e0 + b * NT, r.total - 1u);
+            en[b] = a.ent_in[e < r.lenA ? r.offA + e : r.offB + (e - r.lenA)];
         }
 #pragma unroll
         for (int b = 0; b < kBatch; ++b)
-            if (ok[b]) f(fromA[b], static_cast<int>(en[b].x), static_cast<unsigned>(__uint_as_float(en[b].y) * a.scale_in), k0[b], k1[b]);
+            if (e0 + b * NT < r.total) f(en[b].x, en[b].y);
     }
 }
 
-// ---- row lists of cut s -> row lists of cut s+1: one workgroup (a wavefront, or four for long rows) per row ----------
-// Pass 1 marks the columns the row touches in an LDS bitmap; a scan over the bitmap gives every column its place in the
-// (ascending) row and the row its length; pass 2 adds the contributions into the row's values in LDS (integer units,
-// ds_add_u32); the row leaves as 8-byte pairs.  Where the row goes: the calibration run of a plan places rows with an
-// atomic cursor and records (place, length) per row; every later sweep writes the row to that place (row lengths depend on
-// the pedigree alone) -- 24k same-address device-scope atomics per level cost more than the level itself.
+// exclusive prefix of v over the workgroup (thread order) and the workgroup's total; wsum: NT / 64 ints of LDS
+template <int NT>
+__device__ __forceinline__ int block_scan(int v, int tid, int *wsum, int &total)
+{
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if ((tid & 63) >= d) incl += up;
+    }
+    if constexpr (NT == 64) {
+        total = __shfl(incl, 63);
+        return incl - v;
+    } else {
+        __syncthreads();                                   // (wsum may still be read from the previous scan)
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            const int s = wsum[w];
+            if (w < (tid >> 6)) base += s;
+            total += s;
+        }
+        return base + incl - v;
+    }
+}
+
+// ---- rows of Y_s -> rows of Y_{s+1}: one workgroup (a wavefront, or four for long rows) per member of cut s+1 ----------
+// Pass 1 marks the columns of row i of Psi_{s+1} in an LDS bitmap; a scan over the bitmap gives every column its place in the
+// (ascending) row and the row its length; pass 2 adds the contributions into the row's values in LDS (ds_add_u32); the
+// diagonal of a new member is set from fm; then the row is used where it stands: the kinships its children's diagonals
+// need are looked up (fm_out), and it leaves expanded to the columns of the next cut (a row of Y_{s+1}).
 template <int NT>
 __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
 {
@@ -120,7 +156,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     unsigned *vals = bm + a.wp;
     unsigned short *pre = reinterpret_cast<unsigned short *>(vals + a.cap);
     unsigned short *cols = pre + a.wp;
-    __shared__ unsigned fm_slot, off_slot;
+    __shared__ unsigned off_slot;
     __shared__ int wsum[NT / 64 + 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x;
@@ -129,103 +165,101 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
     const uint2 place = a.fixed ? a.rowd_out[i] : make_uint2(0u, 0u);
+    const unsigned fm_i = (new_i && A != none && B != none) ? a.fm_in[i] : 0u;
     for (int w = tid; w < a.wp; w += NT) bm[w] = 0u;
-    if (tid == 0) fm_slot = 0u;
     __syncthreads();
     // pass 1: which columns
-    for_each_entry<NT>(a, r, tid, [&](bool fromA, int q, unsigned mv, int k0, int k1) {
-        if (fromA && q == B) fm_slot = mv;                              // Psi[A][B] for the diagonal (one thread at most)
-        for (int k = k0; k < k1; ++k) {
-            const unsigned c = a.ch[k] & 0x7fffffffu;
-            atomicOr(&bm[c >> 5], 1u << (c & 31u));
-        }
-    });
+    for_each_entry<NT>(a, r, tid, [&](unsigned c, unsigned) { atomicOr(&bm[c >> 5], 1u << (c & 31u)); });
     if (new_i && tid == 0) atomicOr(&bm[i >> 5], 1u << (i & 31));
     __syncthreads();
     // every thread owns T consecutive bitmap words (T odd: no bank conflicts between the lanes)
     const int T = a.wp / NT, w0 = tid * T;
     int cnt = 0;
     for (int w = w0; w < w0 + T; ++w) cnt += __popc(bm[w]);
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if ((tid & 63) >= d) incl += up;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
-        const int s = wsum[w];
-        if (w < (tid >> 6)) base += s;
-        total += s;
-    }
-    bool bad = total > a.cap;                              // (workgroup-uniform) the row does not fit: the cut is too dense to stay sparse
-    unsigned off = place.x;
-    if (!bad) {
-        if (a.fixed) {
-            bad = static_cast<unsigned>(total) != place.y;
-        } else {
-            if (tid == 0) off_slot = atomicAdd(&a.stat[0], static_cast<unsigned>(total));
-            __syncthreads();
-            off = off_slot;
-            bad = off + static_cast<unsigned>(total) > a.ent_cap || off + static_cast<unsigned>(total) < off;
-        }
-    }
-    if (bad) {
+    int total;
+    int pos = block_scan<NT>(cnt, tid, wsum, total);
+    if (total > a.cap) {                                   // (workgroup-uniform) the row does not fit: the cut is too dense to stay sparse
         if (tid == 0) {
-            atomicOr(&a.stat[2], (a.fixed && total <= a.cap) ? 2u : 1u);
+            atomicOr(&a.stat[2], 1u);
             if (!a.fixed) a.rowd_out[i] = make_uint2(0u, 0u);
         }
         return;
     }
-    {
-        int pos = base + incl - cnt;
-        for (int w = w0; w < w0 + T; ++w) {
-            pre[w] = static_cast<unsigned short>(pos);
-            unsigned bits = bm[w];
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                cols[pos++] = static_cast<unsigned short>(w * 32 + b);
-                bits &= bits - 1u;
-            }
+    for (int w = w0; w < w0 + T; ++w) {
+        pre[w] = static_cast<unsigned short>(pos);
+        unsigned bits = bm[w];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            cols[pos++] = static_cast<unsigned short>(w * 32 + b);
+            bits &= bits - 1u;
         }
     }
     for (int t = tid; t < total; t += NT) vals[t] = 0u;
     __syncthreads();
-    // pass 2: the values, in units of 2^-(2c+3)
+    // pass 2: the values, in units of 2^-(2s+3)
     const unsigned wi = new_i ? 1u : 2u;
-    for_each_entry<NT>(a, r, tid, [&](bool, int, unsigned mv, int k0, int k1) {
-        const unsigned m = mv * wi;
-        for (int k = k0; k < k1; ++k) {
-            const unsigned cw = a.ch[k], c = cw & 0x7fffffffu;
-            if (new_i && c == static_cast<unsigned>(i)) continue;       // the diagonal of a new member is not a sum of this kind
-            const int pos = pre[c >> 5] + __popc(bm[c >> 5] & ((1u << (c & 31u)) - 1u));
-            atomicAdd(&vals[pos], m * ((cw >> 31) + 1u));
-        }
+    for_each_entry<NT>(a, r, tid, [&](unsigned c, unsigned m) {
+        if (new_i && c == static_cast<unsigned>(i)) return;               // the diagonal of a new member is not a sum of this kind
+        const int at = pre[c >> 5] + __popc(bm[c >> 5] & ((1u << (c & 31u)) - 1u));
+        atomicAdd(&vals[at], m * wi);
     });
     __syncthreads();
     if (new_i && tid == 0) {
-        const int pos = pre[i >> 5] + __popc(bm[i >> 5] & ((1u << (i & 31)) - 1u));
-        vals[pos] = a.half_out + ((A != none && B != none) ? 2u * fm_slot : 0u);      // 1/2 + Psi[A][B]/2, src/compute.jl:148-154
+        const int at = pre[i >> 5] + __popc(bm[i >> 5] & ((1u << (i & 31)) - 1u));
+        vals[at] = a.half_out + 2u * fm_i;                                // 1/2 + Psi[A][B]/2 when both parents exist, src/compute.jl:148-154
     }
     __syncthreads();
-    for (int t = tid; t < total; t += NT)
-        a.ent_out[off + t] = make_uint2(static_cast<unsigned>(cols[t]), __float_as_uint(static_cast<float>(vals[t]) * a.unit_out));
-    if (!a.fixed && tid == 0) {
-        a.rowd_out[i] = make_uint2(off, static_cast<unsigned>(total));
-        atomicMax(&a.stat[1], static_cast<unsigned>(total));
+    // the kinship of i with each of its mates: the diagonal of their children in the next cut
+    for (int k = a.mt_off[i] + tid; k < a.mt_off[i + 1]; k += NT) {
+        const uint2 m = a.mt[k];
+        const unsigned word = bm[m.x >> 5], bit = 1u << (m.x & 31u);
+        a.fm_out[m.y] = (word & bit) ? vals[pre[m.x >> 5] + __popc(word & (bit - 1u))] : 0u;
     }
+    // the row leaves as a row of Y_{s+1}: every entry (q, v) goes to the children of q
+    unsigned off = place.x;
+    if (!a.fixed) {                                        // calibration run: the row's length first, then its place
+        int len = 0;
+        for (int t = tid; t < total; t += NT) { const int q = cols[t]; len += a.chn_off[q + 1] - a.chn_off[q]; }
+        int ltot;
+        (void)block_scan<NT>(len, tid, wsum, ltot);
+        if (tid == 0) off_slot = atomicAdd(&a.stat[0], static_cast<unsigned>(ltot));
+        __syncthreads();
+        off = off_slot;
+        if (off + static_cast<unsigned>(ltot) > a.ent_cap || off + static_cast<unsigned>(ltot) < off) {
+            if (tid == 0) { atomicOr(&a.stat[2], 1u); a.rowd_out[i] = make_uint2(0u, 0u); }
+            return;
+        }
+        if (tid == 0) {
+            a.rowd_out[i] = make_uint2(off, static_cast<unsigned>(ltot));
+            atomicMax(&a.stat[1], static_cast<unsigned>(total));
+            atomicAdd(&a.stat[3], static_cast<unsigned>(total));
+        }
+    }
+    const unsigned limit = a.fixed ? place.y : 0xffffffffu;
+    unsigned run = 0u;
+    for (int t0 = 0; t0 < total; t0 += NT) {
+        const int t = t0 + tid;
+        const bool ok = t < total;
+        const int q = ok ? cols[t] : 0;
+        const int k0 = a.chn_off[q], k1 = ok ? a.chn_off[q + 1] : k0;
+        int it_total;
+        unsigned at = run + static_cast<unsigned>(block_scan<NT>(k1 - k0, tid, wsum, it_total));
+        const unsigned v = ok ? vals[t] : 0u;
+        for (int k = k0; k < k1; ++k, ++at) {
+            const unsigned cw = a.chn[k];
+            if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v * ((cw >> 31) + 1u));
+        }
+        run += static_cast<unsigned>(it_total);
+    }
+    if (a.fixed && run != place.y && tid == 0) atomicOr(&a.stat[2], 2u);
 }
 
-// ---- row lists of cut k -> the dense matrix of cut k+1: one workgroup per (row, chunk of columns) ---------------------
+// ---- rows of Y_k -> the dense matrix of cut k+1: one workgroup per (row, chunk of columns) -------------------------------
 // The chunk's entries are accumulated in LDS (integer units) and leave as whole 16-byte stores, zeros included: the step
 // writes what a FULL / SPLIT row kernel writes (columns [0, width) of every row, the all-zero row n) and reads only lists.
 __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
 {
     extern __shared__ unsigned acc[];
-    __shared__ unsigned fm_slot;
     const int tid = threadIdx.x;
     const int i = blockIdx.x / a.n_chunks, chunk = blockIdx.x - i * a.n_chunks;
     const int c0 = chunk * a.chunk_cols;
@@ -242,22 +276,18 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
+    const bool diag_here = new_i && i >= c0 && i < c1;
+    const unsigned fm_i = (diag_here && A != none && B != none) ? a.fm_in[i] : 0u;
     for (int j = 4 * tid; j < c1 - c0; j += 1024) *reinterpret_cast<uint4 *>(acc + j) = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) fm_slot = 0u;
     __syncthreads();
     const unsigned wi = new_i ? 1u : 2u;
-    for_each_entry<256>(a, r, tid, [&](bool fromA, int q, unsigned mv, int k0, int k1) {
-        if (fromA && q == B) fm_slot = mv;
-        const unsigned m = mv * wi;
-        for (int k = k0; k < k1; ++k) {
-            const unsigned cw = a.ch[k];
-            const int c = static_cast<int>(cw & 0x7fffffffu);
-            if (c < c0 || c >= c1 || (new_i && c == i)) continue;
-            atomicAdd(&acc[c - c0], m * ((cw >> 31) + 1u));
-        }
+    for_each_entry<256>(a, r, tid, [&](unsigned cu, unsigned m) {
+        const int c = static_cast<int>(cu);
+        if (c < c0 || c >= c1 || (new_i && c == i)) return;
+        atomicAdd(&acc[c - c0], m * wi);
     });
     __syncthreads();
-    if (new_i && tid == 0 && i >= c0 && i < c1) acc[i - c0] = a.half_out + ((A != none && B != none) ? 2u * fm_slot : 0u);
+    if (diag_here && tid == 0) acc[i - c0] = a.half_out + 2u * fm_i;
     __syncthreads();
     float *orow = a.out + static_cast<long long>(i) * a.ld + c0;
     for (int j = 4 * tid; j < c1 - c0; j += 1024) {
@@ -279,16 +309,21 @@ struct SparseLevels {
     SparseTuning tun;
     std::vector<int> n_of;           // members of cuts 0..S
     std::vector<SparseStepDev> dev;
-    char *blob = nullptr;            // children lists of the S steps
-    std::vector<const int *> ch_off;
+    char *blob = nullptr;            // children and mate lists of the S steps
+    std::vector<const int *> ch_off, mt_off;
     std::vector<const unsigned *> ch;
+    std::vector<const uint2 *> mt;
+    std::vector<int> n_ch;           // entries of ch per step
     uint2 *ent[2] = {nullptr, nullptr};
     uint2 *rowd_blob = nullptr;      // row descriptors of cuts 0..S-1, written by the calibration run and kept
     std::vector<uint2 *> rowd;
+    unsigned *fm_blob = nullptr;     // fm[c], c = 0..S-1: one word per member of cut c+1
+    std::vector<unsigned *> fm;
     size_t ent_cap = 0;
     unsigned *stat = nullptr;        // 4 words per cut
     unsigned *stat_host = nullptr;   // pinned copy of them, fetched at the end of a sweep
-    std::vector<long long> nnz;      // per cut 0..S (-1 unknown)
+    std::vector<long long> nnz;      // non-zero entries of Psi_c per cut 0..S (-1 unknown)
+    std::vector<long long> n_ent;    // entries of Y_c
     std::vector<int> max_row;
     int cap_cal = 0;
     double bytes = 0.0;
@@ -330,67 +365,88 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     sl->S = S; sl->tun = tun; sl->dev.assign(dev.begin(), dev.begin() + S);
     sl->n_of.resize(S + 1);
     for (int c = 0; c <= S; ++c) sl->n_of[c] = static_cast<int>(plan.cut_sizes[c]);
-    sl->nnz.assign(S + 1, -1); sl->max_row.assign(S + 1, 0);
+    sl->nnz.assign(S + 1, -1); sl->n_ent.assign(S + 1, -1); sl->max_row.assign(S + 1, 0);
     sl->nnz[0] = sl->n_of[0]; sl->max_row[0] = 1;
-    // children lists (counting sort of the members of cut s+1 by their sources)
+    // children lists (counting sort of the members of cut s+1 by their sources) and mate lists (new members with two parents, by
+    // their A source)
     size_t total = 256;
-    std::vector<std::vector<int>> offs(S);
+    std::vector<std::vector<int>> offs(S), moffs(S);
     std::vector<std::vector<unsigned>> chs(S);
+    std::vector<std::vector<uint2>> mts(S);
     for (int s = 0; s < S; ++s) {
         const LevelStep &st = plan.steps[s];
         const int n_prev = static_cast<int>(st.n_prev), n = static_cast<int>(st.n);
-        std::vector<int> &off = offs[s];
+        std::vector<int> &off = offs[s], &moff = moffs[s];
         off.assign(static_cast<size_t>(n_prev) + 2, 0);
+        moff.assign(static_cast<size_t>(n_prev) + 2, 0);
         for (int i = 0; i < n; ++i) {
             if (st.srcA[i] != n_prev) off[st.srcA[i] + 1]++;
             if (st.srcB[i] != n_prev) off[st.srcB[i] + 1]++;
+            if (st.ord[i] < 0 && st.srcA[i] != n_prev && st.srcB[i] != n_prev) moff[st.srcA[i] + 1]++;
         }
-        for (int q = 0; q <= n_prev; ++q) off[q + 1] += off[q];
+        for (int q = 0; q <= n_prev; ++q) { off[q + 1] += off[q]; moff[q + 1] += moff[q]; }
         std::vector<unsigned> &ch = chs[s];
+        std::vector<uint2> &mt = mts[s];
         ch.resize(static_cast<size_t>(off[n_prev]) + 1);
-        std::vector<int> fill(off.begin(), off.end() - 1);
+        mt.resize(static_cast<size_t>(moff[n_prev]) + 1);
+        std::vector<int> fill(off.begin(), off.end() - 1), mfill(moff.begin(), moff.end() - 1);
         for (int i = 0; i < n; ++i) {
             const unsigned w = static_cast<unsigned>(i) | (st.ord[i] < 0 ? 0u : 0x80000000u);
             if (st.srcA[i] != n_prev) ch[fill[st.srcA[i]]++] = w;
             if (st.srcB[i] != n_prev) ch[fill[st.srcB[i]]++] = w;
+            if (st.ord[i] < 0 && st.srcA[i] != n_prev && st.srcB[i] != n_prev)
+                mt[mfill[st.srcA[i]]++] = make_uint2(static_cast<unsigned>(st.srcB[i]), static_cast<unsigned>(i));
         }
-        total += al256(off.size() * sizeof(int)) + al256(ch.size() * sizeof(unsigned));
+        sl->n_ch.push_back(off[n_prev]);
+        total += al256(off.size() * sizeof(int)) + al256(ch.size() * sizeof(unsigned)) + al256(moff.size() * sizeof(int)) + al256(mt.size() * sizeof(uint2));
     }
+    sl->n_ent[0] = sl->n_ch[0];
     auto fail = [&](const std::string &m) { err = m; sparse_levels_destroy(sl); return static_cast<SparseLevels *>(nullptr); };
     if (hipMalloc(reinterpret_cast<void **>(&sl->blob), total) != hipSuccess) return fail("hipMalloc (children lists) failed");
     std::vector<char> host(total, 0);
     size_t o = 0;
-    sl->ch_off.resize(S); sl->ch.resize(S);
+    sl->ch_off.resize(S); sl->ch.resize(S); sl->mt_off.resize(S); sl->mt.resize(S);
+    auto put = [&](const void *src, size_t bytes) -> const char * {
+        std::memcpy(host.data() + o, src, bytes);
+        const char *d = sl->blob + o;
+        o += al256(bytes);
+        return d;
+    };
     for (int s = 0; s < S; ++s) {
-        std::memcpy(host.data() + o, offs[s].data(), offs[s].size() * sizeof(int));
-        sl->ch_off[s] = reinterpret_cast<const int *>(sl->blob + o);
-        o += al256(offs[s].size() * sizeof(int));
-        std::memcpy(host.data() + o, chs[s].data(), chs[s].size() * sizeof(unsigned));
-        sl->ch[s] = reinterpret_cast<const unsigned *>(sl->blob + o);
-        o += al256(chs[s].size() * sizeof(unsigned));
+        sl->ch_off[s] = reinterpret_cast<const int *>(put(offs[s].data(), offs[s].size() * sizeof(int)));
+        sl->ch[s] = reinterpret_cast<const unsigned *>(put(chs[s].data(), chs[s].size() * sizeof(unsigned)));
+        sl->mt_off[s] = reinterpret_cast<const int *>(put(moffs[s].data(), moffs[s].size() * sizeof(int)));
+        sl->mt[s] = reinterpret_cast<const uint2 *>(put(mts[s].data(), mts[s].size() * sizeof(uint2)));
     }
     if (hipMemcpyAsync(sl->blob, host.data(), total, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return fail("upload of the children lists failed");
-    // arenas: cuts 1..S-1 may be kept sparse; the calibration also writes the cut that turns out too dense (until the arena is full)
+    // arenas: the rows of Y of cuts 0..S-1 (a non-zero entry of Psi has about two children; the calibration also writes the cut
+    // that turns out too dense, until the arena is full)
     int n_max = 0;
-    for (int c = 0; c < S; ++c) n_max = std::max(n_max, sl->n_of[c]);
+    for (int c = 0; c <= S; ++c) n_max = std::max(n_max, sl->n_of[c]);
     const double share = tun.force_k >= 0 ? 1.0 : std::min(1.0, std::max(1, tun.max_permille) / 1000.0);
-    double want = share * static_cast<double>(n_max) * static_cast<double>(n_max) + 2.0 * n_max + 1024.0;
+    double want = 3.0 * share * static_cast<double>(n_max) * static_cast<double>(n_max) + 8.0 * n_max + 1024.0;
     want = std::min(want, 4.0e9);                      // (32-bit cursor)
     sl->ent_cap = static_cast<size_t>(want);
     for (int b = 0; b < 2; ++b)
         if (hipMalloc(reinterpret_cast<void **>(&sl->ent[b]), sl->ent_cap * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row-list arena) failed");
-    size_t rowd_total = 0;
-    for (int c = 0; c < S; ++c) rowd_total += (static_cast<size_t>(sl->n_of[c]) + 32) / 32 * 32;
+    size_t rowd_total = 0, fm_total = 0;
+    auto pad32 = [](int n) { return (static_cast<size_t>(n) + 32) / 32 * 32; };
+    for (int c = 0; c < S; ++c) { rowd_total += pad32(sl->n_of[c]); fm_total += pad32(sl->n_of[c + 1]); }
     if (hipMalloc(reinterpret_cast<void **>(&sl->rowd_blob), rowd_total * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row descriptors) failed");
-    sl->rowd.resize(S);
-    for (size_t c = 0, at = 0; c < static_cast<size_t>(S); ++c) { sl->rowd[c] = sl->rowd_blob + at; at += (static_cast<size_t>(sl->n_of[c]) + 32) / 32 * 32; }
+    if (hipMalloc(reinterpret_cast<void **>(&sl->fm_blob), fm_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (parents' kinships) failed");
+    sl->rowd.resize(S); sl->fm.resize(S);
+    for (size_t c = 0, at = 0, fat = 0; c < static_cast<size_t>(S); ++c) {
+        sl->rowd[c] = sl->rowd_blob + at; at += pad32(sl->n_of[c]);
+        sl->fm[c] = sl->fm_blob + fat; fat += pad32(sl->n_of[c + 1]);
+    }
     if (hipMalloc(reinterpret_cast<void **>(&sl->stat), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (counters) failed");
     if (hipHostMalloc(reinterpret_cast<void **>(&sl->stat_host), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return fail("hipHostMalloc (counters) failed");
     std::memset(sl->stat_host, 0, 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned));
-    sl->bytes = static_cast<double>(total) + 2.0 * sl->ent_cap * sizeof(uint2) + static_cast<double>(rowd_total * sizeof(uint2));
-    sl->cap_cal = std::min(8192, (std::max(n_max, sl->n_of[S]) + 63) / 64 * 64);
+    sl->bytes = static_cast<double>(total) + 2.0 * sl->ent_cap * sizeof(uint2) + static_cast<double>(rowd_total * sizeof(uint2) + fm_total * sizeof(unsigned));
+    sl->cap_cal = std::min(8192, (n_max + 63) / 64 * 64);
+    if (static_cast<size_t>(sl->n_ch[0]) > sl->ent_cap) return fail("sparse levels: arena smaller than the first cut");
     return sl;
 }
 
@@ -400,41 +456,47 @@ void sparse_levels_destroy(SparseLevels *sl)
     if (sl->blob) (void)hipFree(sl->blob);
     for (int b = 0; b < 2; ++b) if (sl->ent[b]) (void)hipFree(sl->ent[b]);
     if (sl->rowd_blob) (void)hipFree(sl->rowd_blob);
+    if (sl->fm_blob) (void)hipFree(sl->fm_blob);
     if (sl->stat) (void)hipFree(sl->stat);
     if (sl->stat_host) (void)hipHostFree(sl->stat_host);
     delete sl;
 }
 
+// arguments of step s (source cut s as rows of Y_s in arena s & 1)
 static SpArgs args_for(const SparseLevels *sl, int s)
 {
     SpArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.ent_in = sl->ent[s & 1]; a.rowd_in = sl->rowd[s];
-    a.ent_out = sl->ent[(s + 1) & 1]; a.rowd_out = s + 1 < sl->S ? sl->rowd[s + 1] : nullptr;
-    a.fixed = sl->calibrated ? 1 : 0;
+    a.ent_in = sl->ent[s & 1]; a.rowd_in = sl->rowd[s]; a.fm_in = sl->fm[s];
     a.srcA = sl->dev[s].srcA; a.srcB = sl->dev[s].srcB; a.ord = sl->dev[s].ord;
-    a.ch_off = sl->ch_off[s]; a.ch = sl->ch[s];
     a.n_prev = sl->n_of[s]; a.n = sl->n_of[s + 1];
-    a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu));
-    a.scale_in = std::ldexp(1.0f, 2 * s + 1);
-    a.unit_out = std::ldexp(1.0f, -(2 * s + 3));
     a.half_out = 1u << (2 * s + 2);
+    a.unit_out = std::ldexp(1.0f, -(2 * s + 3));
     a.stat = sl->stat + 4 * (s + 1);
+    if (s + 1 < sl->S) {                                   // (the row-list form of cut s+1 needs the lists of step s+1)
+        a.ent_out = sl->ent[(s + 1) & 1]; a.rowd_out = sl->rowd[s + 1];
+        a.chn_off = sl->ch_off[s + 1]; a.chn = sl->ch[s + 1];
+        a.mt_off = sl->mt_off[s + 1]; a.mt = sl->mt[s + 1];
+        a.fm_out = sl->fm[s + 1];
+    }
+    a.fixed = sl->calibrated ? 1 : 0;
+    a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu));
     return a;
 }
 
 static int launch_step(SparseLevels *sl, int s, int cap, hipStream_t stream, std::string &err)
 {
     if (s == 0) {
-        const int n0 = sl->n_of[0], n_stat = 4 * (sl->S + 1);
-        hipLaunchKernelGGL(sparse_identity_kernel, dim3((std::max(n0, n_stat) + 255) / 256), dim3(256), 0, stream, sl->ent[0], sl->rowd[0], n0,
-                           sl->stat, n_stat);
+        const int n0 = sl->n_of[0], n1 = sl->n_of[1], n_stat = 4 * (sl->S + 1);
+        const int m = std::max(std::max(n0, n1), std::max(n_stat, sl->n_ch[0]));
+        hipLaunchKernelGGL(sparse_identity_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, sl->ent[0], sl->rowd[0], sl->ch_off[0], sl->ch[0], n0,
+                           sl->n_ch[0], sl->dev[0].srcA, sl->dev[0].srcB, sl->dev[0].ord, sl->fm[0], n1, sl->stat, n_stat);
         SP_TRY(hipGetLastError());
     }
     SpArgs a = args_for(sl, s);
     a.cap = cap;
-    // long source rows: four wavefronts per row (a thread walks entries / (4 x 256) dependent chains instead of entries / (4 x 64))
-    const bool wide = sl->nnz[s] > 96ll * sl->n_of[s];
+    // long source rows: four wavefronts per row
+    const bool wide = sl->n_ent[s] > 192ll * sl->n_of[s];
     a.wp = wp_for(a.n, wide ? 256 : 64);
     const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
     if (wide) hipLaunchKernelGGL(sparse_step_kernel<256>, dim3(static_cast<unsigned>(a.n)), dim3(256), lds, stream, a);
@@ -450,7 +512,7 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     sl->k = -1;
     if (sl->tun.force_k == -1) { sl->calibrated = true; return GENPHI_OK; }
     int k = 0;
-    for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be a sparse source only when step s+1 is eligible too
+    for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be kept as lists only when step s+1 is eligible too
         if (sl->tun.force_k >= 0 && s + 1 > sl->tun.force_k) break;
         const int rc = launch_step(sl, s, sl->cap_cal, stream, err);
         if (rc) return rc;
@@ -459,10 +521,11 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         SP_TRY(hipStreamSynchronize(stream));
         const double n = static_cast<double>(sl->n_of[s + 1]);
         const bool ovf = st[2] != 0;
-        sl->nnz[s + 1] = ovf ? -1 : static_cast<long long>(st[0]);
+        sl->nnz[s + 1] = ovf ? -1 : static_cast<long long>(st[3]);
+        sl->n_ent[s + 1] = ovf ? -1 : static_cast<long long>(st[0]);
         sl->max_row[s + 1] = static_cast<int>(st[1]);
         if (ovf) break;
-        if (sl->tun.force_k < 0 && static_cast<double>(st[0]) > sl->tun.max_permille / 1000.0 * n * n) break;
+        if (sl->tun.force_k < 0 && static_cast<double>(st[3]) > sl->tun.max_permille / 1000.0 * n * n) break;
         k = s + 1;
     }
     sl->calibrated = true;                                 // (from here on rows go where this run put them)
@@ -490,8 +553,10 @@ int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long
     if (!sl || sl->k < 1) { err = "sparse_levels_enqueue_dense: no sparse cut"; return GENPHI_ERR_ARG; }
     SpArgs a = args_for(sl, sl->k);
     a.out = out; a.ld = ld; a.width = static_cast<int>(width);
-    a.chunk_cols = std::max(1024, std::min(sl->tun.chunk_cols, 15360) / 1024 * 1024);
-    // (the "none" row spans the pitch, the member rows the width the caller names)
+    // columns per workgroup: the member rows in as few equal chunks as the budget allows (the "none" row spans the pitch)
+    const int budget = std::max(1024, std::min(sl->tun.chunk_cols, 15360) / 1024 * 1024);
+    const int row_chunks = static_cast<int>((width + budget - 1) / budget);
+    a.chunk_cols = static_cast<int>(((width + row_chunks - 1) / row_chunks + 255) / 256 * 256);
     a.n_chunks = static_cast<int>((std::max(ld, width) + a.chunk_cols - 1) / a.chunk_cols);
     const size_t lds = static_cast<size_t>(a.chunk_cols) * sizeof(unsigned);
     hipLaunchKernelGGL(sparse_dense_kernel, dim3(static_cast<unsigned>((a.n + 1)) * a.n_chunks), dim3(256), lds, stream, a);
