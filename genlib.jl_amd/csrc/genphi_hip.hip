@@ -2026,6 +2026,7 @@ struct Tuning {
     int sparse_permille = -1;      // GENPHI_SPARSE_PERMILLE  tuning: a cut stays sparse while at most this share (1/1000) of its entries is non-zero
     int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
     int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
+    int sparse_classes = -1;       // GENPHI_SPARSE_CLASSES   A/B + test: 1 / 0 = a row-list step is always / never one launch per class of row lengths (default: where lengths differ much)
 };
 
 static Tuning tuning_from_env()
@@ -2083,6 +2084,7 @@ static Tuning tuning_from_env()
     t.sparse_permille = geti("GENPHI_SPARSE_PERMILLE", -1);
     t.sparse_min_cut = geti("GENPHI_SPARSE_MIN_CUT", -1);
     t.sparse_chunk = geti("GENPHI_SPARSE_CHUNK", 0);
+    t.sparse_classes = geti("GENPHI_SPARSE_CLASSES", -1);
     return t;
 }
 
@@ -3391,6 +3393,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             if (p->tun.sparse_permille > 0) stn.max_permille = p->tun.sparse_permille;
             if (p->tun.sparse_min_cut >= 0) stn.min_cut = p->tun.sparse_min_cut;
             if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
+            stn.classes = p->tun.sparse_classes;
             std::string serr;
             p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
             if (p->sparse) {

@@ -38,11 +38,13 @@ struct SparseStepDev {                        // device index arrays of level st
 };
 
 struct SparseTuning {
-    int max_permille = 80;     // a cut stays sparse while its non-zero entries are at most this share (in 1/1000) of n^2
+    int max_permille = 200;    // the calibration run stops at the first cut with more than this share (in 1/1000) of non-zero entries; which
+                               // of the cuts before it is the last sparse one is a matter of estimated times (sparse_levels.hip)
     int force_k = -2;          // test / A-B hook: -2 = by calibration; -1 = never sparse; k >= 0: cuts 0..k sparse whatever the counts say
                                // (clamped to what is eligible)
     int min_cut = 1536;        // ... and only when some cut of the sparse run has at least this many members (narrower levels are launch-bound)
     int chunk_cols = 8192;     // columns per workgroup of the sparse -> dense step
+    int classes = -1;          // a launch per class of row lengths: -1 = where the rows of a cut differ much in length, 1 / 0 = always / never (A/B hook)
 };
 
 struct SparseLevels;           // opaque (sparse_levels.hip)

@@ -28,8 +28,12 @@
 #include "sparse_levels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <numeric>
 
 #include "../../include/genphi.h"
 
@@ -57,6 +61,8 @@ struct SpArgs {
     const int *mt_off;            // mates of member p of cut s+1: mt[mt_off[p] .. mt_off[p + 1]) = (B, i) for every new member i of
     const uint2 *mt;              //   cut s+2 with A_i = p and a second parent B
     unsigned *fm_out;             // per member of cut s+2
+    const int *rows;              // the members this launch computes (nullptr: member = workgroup index)
+    unsigned *rnz_out;            // (calibration run) non-zero entries of every row of Psi_{s+1}
     int wp;                       // bitmap words in LDS: workgroup size x an odd number
     int cap;                      // entries of one row of Psi_{s+1} the LDS holds
     unsigned *stat;               // [0] entries of Y written so far, [1] longest row of Psi, [2] 1 = a row or the arena overflowed, 2 = a row's
@@ -96,18 +102,38 @@ __device__ __forceinline__ SrcRows src_rows(const SpArgs &a, int A, int B)
     return SrcRows{ra.x, ra.y, rb.x, ra.y + rb.y};
 }
 
-// the entries of the (<= 2) source rows of an output row as ONE index space: contiguous, coalesced 8-byte loads
-template <int NT, class F>
-__device__ __forceinline__ void for_each_entry(const SpArgs &a, const SrcRows &r, int tid, F &&f)
+// The entries of the (<= 2) source rows of an output row as ONE index space: contiguous, coalesced 8-byte loads.  The first kBatch
+// entries of every thread stay in registers between the passes of the row-list step (most rows have no more); the rest is read again.
+constexpr int kBatch = 4;
+
+template <int NT>
+struct EntryCache {
+    uint2 en[kBatch];
+};
+
+__device__ __forceinline__ uint2 load_entry(const SpArgs &a, const SrcRows &r, unsigned e)
 {
-    constexpr int kBatch = 4;
-    for (unsigned e0 = tid; e0 < r.total; e0 += kBatch * NT) {
+    return a.ent_in[e < r.lenA ? r.offA + e : r.offB + (e - r.lenA)];
+}
+
+template <int NT>
+__device__ __forceinline__ void load_first(const SpArgs &a, const SrcRows &r, int tid, EntryCache<NT> &c)
+{
+    if (r.total == 0u) return;
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) c.en[b] = load_entry(a, r, min(static_cast<unsigned>(tid + b * NT), r.total - 1u));
+}
+
+template <int NT, class F>
+__device__ __forceinline__ void for_each_entry(const SpArgs &a, const SrcRows &r, int tid, const EntryCache<NT> &c, F &&f)
+{
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b)
+        if (static_cast<unsigned>(tid + b * NT) < r.total) f(c.en[b].x, c.en[b].y);
+    for (unsigned e0 = tid + kBatch * NT; e0 < r.total; e0 += kBatch * NT) {
         uint2 en[kBatch];
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            const unsigned e = min(e0 + b * NT, r.total - 1u);
-            en[b] = a.ent_in[e < r.lenA ? r.offA + e : r.offB + (e - r.lenA)];
-        }
+        for (int b = 0; b < kBatch; ++b) en[b] = load_entry(a, r, min(e0 + b * NT, r.total - 1u));
 #pragma unroll
         for (int b = 0; b < kBatch; ++b)
             if (e0 + b * NT < r.total) f(en[b].x, en[b].y);
@@ -159,17 +185,20 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     __shared__ unsigned off_slot;
     __shared__ int wsum[NT / 64 + 1];
     const int tid = threadIdx.x;
-    const int i = blockIdx.x;
+    const int i = a.rows ? a.rows[blockIdx.x] : static_cast<int>(blockIdx.x);
     const int A = a.srcA[i], B = a.srcB[i];
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
+    EntryCache<NT> ec;
+    load_first<NT>(a, r, tid, ec);
     const uint2 place = a.fixed ? a.rowd_out[i] : make_uint2(0u, 0u);
     const unsigned fm_i = (new_i && A != none && B != none) ? a.fm_in[i] : 0u;
+    const int mt0 = a.mt_off[i], mt1 = a.mt_off[i + 1];
     for (int w = tid; w < a.wp; w += NT) bm[w] = 0u;
     __syncthreads();
     // pass 1: which columns
-    for_each_entry<NT>(a, r, tid, [&](unsigned c, unsigned) { atomicOr(&bm[c >> 5], 1u << (c & 31u)); });
+    for_each_entry<NT>(a, r, tid, ec, [&](unsigned c, unsigned) { atomicOr(&bm[c >> 5], 1u << (c & 31u)); });
     if (new_i && tid == 0) atomicOr(&bm[i >> 5], 1u << (i & 31));
     __syncthreads();
     // every thread owns T consecutive bitmap words (T odd: no bank conflicts between the lanes)
@@ -181,7 +210,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     if (total > a.cap) {                                   // (workgroup-uniform) the row does not fit: the cut is too dense to stay sparse
         if (tid == 0) {
             atomicOr(&a.stat[2], 1u);
-            if (!a.fixed) a.rowd_out[i] = make_uint2(0u, 0u);
+            if (!a.fixed) { a.rowd_out[i] = make_uint2(0u, 0u); a.rnz_out[i] = 0u; }
         }
         return;
     }
@@ -198,7 +227,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     __syncthreads();
     // pass 2: the values, in units of 2^-(2s+3)
     const unsigned wi = new_i ? 1u : 2u;
-    for_each_entry<NT>(a, r, tid, [&](unsigned c, unsigned m) {
+    for_each_entry<NT>(a, r, tid, ec, [&](unsigned c, unsigned m) {
         if (new_i && c == static_cast<unsigned>(i)) return;               // the diagonal of a new member is not a sum of this kind
         const int at = pre[c >> 5] + __popc(bm[c >> 5] & ((1u << (c & 31u)) - 1u));
         atomicAdd(&vals[at], m * wi);
@@ -210,47 +239,63 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     }
     __syncthreads();
     // the kinship of i with each of its mates: the diagonal of their children in the next cut
-    for (int k = a.mt_off[i] + tid; k < a.mt_off[i + 1]; k += NT) {
+    for (int k = mt0 + tid; k < mt1; k += NT) {
         const uint2 m = a.mt[k];
         const unsigned word = bm[m.x >> 5], bit = 1u << (m.x & 31u);
         a.fm_out[m.y] = (word & bit) ? vals[pre[m.x >> 5] + __popc(word & (bit - 1u))] : 0u;
     }
-    // the row leaves as a row of Y_{s+1}: every entry (q, v) goes to the children of q
+    // the row leaves as a row of Y_{s+1}: every entry (q, v) goes to the children of q.  kBatch entries per thread at a time, their
+    // children ranges loaded together (entry -> range -> children are dependent round trips through L2), one scan per batch; the
+    // order of a row's entries in Y is free.
+    auto expand = [&](bool store, unsigned off, unsigned limit) -> unsigned {
+        unsigned run = 0u;
+        for (int t0 = 0; t0 < total; t0 += kBatch * NT) {
+            int k0[kBatch], k1[kBatch];
+            unsigned v[kBatch];
+            int mine = 0;
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const int t = t0 + b * NT + tid;
+                const bool ok = t < total;
+                const int q = ok ? cols[t] : 0;
+                v[b] = ok ? vals[t] : 0u;
+                k0[b] = a.chn_off[q];
+                k1[b] = ok ? a.chn_off[q + 1] : k0[b];
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) mine += k1[b] - k0[b];
+            int it_total;
+            unsigned at = run + static_cast<unsigned>(block_scan<NT>(mine, tid, wsum, it_total));
+            if (store) {
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b)
+                    for (int k = k0[b]; k < k1[b]; ++k, ++at) {
+                        const unsigned cw = a.chn[k];
+                        if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v[b] * ((cw >> 31) + 1u));
+                    }
+            }
+            run += static_cast<unsigned>(it_total);
+        }
+        return run;
+    };
     unsigned off = place.x;
     if (!a.fixed) {                                        // calibration run: the row's length first, then its place
-        int len = 0;
-        for (int t = tid; t < total; t += NT) { const int q = cols[t]; len += a.chn_off[q + 1] - a.chn_off[q]; }
-        int ltot;
-        (void)block_scan<NT>(len, tid, wsum, ltot);
-        if (tid == 0) off_slot = atomicAdd(&a.stat[0], static_cast<unsigned>(ltot));
+        const unsigned ltot = expand(false, 0u, 0u);
+        if (tid == 0) off_slot = atomicAdd(&a.stat[0], ltot);
         __syncthreads();
         off = off_slot;
-        if (off + static_cast<unsigned>(ltot) > a.ent_cap || off + static_cast<unsigned>(ltot) < off) {
-            if (tid == 0) { atomicOr(&a.stat[2], 1u); a.rowd_out[i] = make_uint2(0u, 0u); }
+        if (off + ltot > a.ent_cap || off + ltot < off) {
+            if (tid == 0) { atomicOr(&a.stat[2], 1u); a.rowd_out[i] = make_uint2(0u, 0u); a.rnz_out[i] = 0u; }
             return;
         }
         if (tid == 0) {
-            a.rowd_out[i] = make_uint2(off, static_cast<unsigned>(ltot));
+            a.rowd_out[i] = make_uint2(off, ltot);
+            a.rnz_out[i] = static_cast<unsigned>(total);
             atomicMax(&a.stat[1], static_cast<unsigned>(total));
             atomicAdd(&a.stat[3], static_cast<unsigned>(total));
         }
     }
-    const unsigned limit = a.fixed ? place.y : 0xffffffffu;
-    unsigned run = 0u;
-    for (int t0 = 0; t0 < total; t0 += NT) {
-        const int t = t0 + tid;
-        const bool ok = t < total;
-        const int q = ok ? cols[t] : 0;
-        const int k0 = a.chn_off[q], k1 = ok ? a.chn_off[q + 1] : k0;
-        int it_total;
-        unsigned at = run + static_cast<unsigned>(block_scan<NT>(k1 - k0, tid, wsum, it_total));
-        const unsigned v = ok ? vals[t] : 0u;
-        for (int k = k0; k < k1; ++k, ++at) {
-            const unsigned cw = a.chn[k];
-            if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v * ((cw >> 31) + 1u));
-        }
-        run += static_cast<unsigned>(it_total);
-    }
+    const unsigned run = expand(true, off, a.fixed ? place.y : 0xffffffffu);
     if (a.fixed && run != place.y && tid == 0) atomicOr(&a.stat[2], 2u);
 }
 
@@ -281,7 +326,9 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     for (int j = 4 * tid; j < c1 - c0; j += 1024) *reinterpret_cast<uint4 *>(acc + j) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const unsigned wi = new_i ? 1u : 2u;
-    for_each_entry<256>(a, r, tid, [&](unsigned cu, unsigned m) {
+    EntryCache<256> ec;
+    load_first<256>(a, r, tid, ec);
+    for_each_entry<256>(a, r, tid, ec, [&](unsigned cu, unsigned m) {
         const int c = static_cast<int>(cu);
         if (c < c0 || c >= c1 || (new_i && c == i)) return;
         atomicAdd(&acc[c - c0], m * wi);
@@ -319,6 +366,13 @@ struct SparseLevels {
     std::vector<uint2 *> rowd;
     unsigned *fm_blob = nullptr;     // fm[c], c = 0..S-1: one word per member of cut c+1
     std::vector<unsigned *> fm;
+    // rows of a cut by length (calibration): rnz[c][i] = non-zero entries of row i of Psi_c; order[c] = the members of cut c, longest row
+    // first; cls[c][j] = first position in order[c] of the rows of class j (0: more than 1024 entries, 1: more than 256, 2: the rest; [3] = n)
+    unsigned *rnz_blob = nullptr;
+    int *order_blob = nullptr;
+    std::vector<unsigned *> rnz;
+    std::vector<int *> order;
+    std::vector<std::array<int, 4>> cls;
     size_t ent_cap = 0;
     unsigned *stat = nullptr;        // 4 words per cut
     unsigned *stat_host = nullptr;   // pinned copy of them, fetched at the end of a sweep
@@ -435,9 +489,11 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     for (int c = 0; c < S; ++c) { rowd_total += pad32(sl->n_of[c]); fm_total += pad32(sl->n_of[c + 1]); }
     if (hipMalloc(reinterpret_cast<void **>(&sl->rowd_blob), rowd_total * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row descriptors) failed");
     if (hipMalloc(reinterpret_cast<void **>(&sl->fm_blob), fm_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (parents' kinships) failed");
-    sl->rowd.resize(S); sl->fm.resize(S);
+    if (hipMalloc(reinterpret_cast<void **>(&sl->rnz_blob), rowd_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (row lengths) failed");
+    if (hipMalloc(reinterpret_cast<void **>(&sl->order_blob), rowd_total * sizeof(int)) != hipSuccess) return fail("hipMalloc (row order) failed");
+    sl->rowd.resize(S); sl->fm.resize(S); sl->rnz.resize(S); sl->order.resize(S); sl->cls.assign(S, std::array<int, 4>{0, 0, 0, 0});
     for (size_t c = 0, at = 0, fat = 0; c < static_cast<size_t>(S); ++c) {
-        sl->rowd[c] = sl->rowd_blob + at; at += pad32(sl->n_of[c]);
+        sl->rowd[c] = sl->rowd_blob + at; sl->rnz[c] = sl->rnz_blob + at; sl->order[c] = sl->order_blob + at; at += pad32(sl->n_of[c]);
         sl->fm[c] = sl->fm_blob + fat; fat += pad32(sl->n_of[c + 1]);
     }
     if (hipMalloc(reinterpret_cast<void **>(&sl->stat), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (counters) failed");
@@ -457,6 +513,8 @@ void sparse_levels_destroy(SparseLevels *sl)
     for (int b = 0; b < 2; ++b) if (sl->ent[b]) (void)hipFree(sl->ent[b]);
     if (sl->rowd_blob) (void)hipFree(sl->rowd_blob);
     if (sl->fm_blob) (void)hipFree(sl->fm_blob);
+    if (sl->rnz_blob) (void)hipFree(sl->rnz_blob);
+    if (sl->order_blob) (void)hipFree(sl->order_blob);
     if (sl->stat) (void)hipFree(sl->stat);
     if (sl->stat_host) (void)hipHostFree(sl->stat_host);
     delete sl;
@@ -478,31 +536,55 @@ static SpArgs args_for(const SparseLevels *sl, int s)
         a.chn_off = sl->ch_off[s + 1]; a.chn = sl->ch[s + 1];
         a.mt_off = sl->mt_off[s + 1]; a.mt = sl->mt[s + 1];
         a.fm_out = sl->fm[s + 1];
+        a.rnz_out = sl->rnz[s + 1];
     }
     a.fixed = sl->calibrated ? 1 : 0;
     a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu));
     return a;
 }
 
-static int launch_step(SparseLevels *sl, int s, int cap, hipStream_t stream, std::string &err)
+static int launch_identity(SparseLevels *sl, hipStream_t stream, std::string &err)
 {
-    if (s == 0) {
-        const int n0 = sl->n_of[0], n1 = sl->n_of[1], n_stat = 4 * (sl->S + 1);
-        const int m = std::max(std::max(n0, n1), std::max(n_stat, sl->n_ch[0]));
-        hipLaunchKernelGGL(sparse_identity_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, sl->ent[0], sl->rowd[0], sl->ch_off[0], sl->ch[0], n0,
-                           sl->n_ch[0], sl->dev[0].srcA, sl->dev[0].srcB, sl->dev[0].ord, sl->fm[0], n1, sl->stat, n_stat);
-        SP_TRY(hipGetLastError());
-    }
-    SpArgs a = args_for(sl, s);
-    a.cap = cap;
-    // long source rows: four wavefronts per row
-    const bool wide = sl->n_ent[s] > 192ll * sl->n_of[s];
-    a.wp = wp_for(a.n, wide ? 256 : 64);
-    const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
-    if (wide) hipLaunchKernelGGL(sparse_step_kernel<256>, dim3(static_cast<unsigned>(a.n)), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(sparse_step_kernel<64>, dim3(static_cast<unsigned>(a.n)), dim3(64), lds, stream, a);
+    const int n0 = sl->n_of[0], n1 = sl->n_of[1], n_stat = 4 * (sl->S + 1);
+    const int m = std::max(std::max(n0, n1), std::max(n_stat, sl->n_ch[0]));
+    hipLaunchKernelGGL(sparse_identity_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, sl->ent[0], sl->rowd[0], sl->ch_off[0], sl->ch[0], n0,
+                       sl->n_ch[0], sl->dev[0].srcA, sl->dev[0].srcB, sl->dev[0].ord, sl->fm[0], n1, sl->stat, n_stat);
     SP_TRY(hipGetLastError());
     return GENPHI_OK;
+}
+
+// one launch of the row-list step: n_rows members (rows == nullptr: all of them, in order), `cap` entries per row in LDS, four
+// wavefronts per row when `wide`
+static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int cap, bool wide, hipStream_t stream, std::string &err)
+{
+    if (n_rows <= 0) return GENPHI_OK;
+    SpArgs a = args_for(sl, s);
+    a.rows = rows;
+    a.cap = cap;
+    a.wp = wp_for(a.n, wide ? 256 : 64);
+    const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
+    if (wide) hipLaunchKernelGGL(sparse_step_kernel<256>, dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(sparse_step_kernel<64>, dim3(static_cast<unsigned>(n_rows)), dim3(64), lds, stream, a);
+    SP_TRY(hipGetLastError());
+    return GENPHI_OK;
+}
+
+// Rough times (ms) of the forms a level step can take, from the counts of the calibration run: what the choice of the last sparse cut
+// rests on.  The rates are measured ones (MI355X, profiles/): a row-list step moves its lists at ~2 TB/s (it is bound by dependent
+// round trips, not by bytes), the sparse -> dense step writes at ~5 TB/s and reads two lists per row, a dense level runs at ~0.6 of 8 TB/s.
+static double t_list_step(const SparseLevels *sl, int s)
+{
+    return 8.0 * (2.0 * static_cast<double>(sl->n_ent[s]) + static_cast<double>(sl->n_ent[s + 1])) / 2.0e9 + 0.010;
+}
+static double t_dense_from_lists(const SparseLevels *sl, int k)
+{
+    const double n = sl->n_of[k + 1];
+    return 4.0 * n * n / 5.0e9 + 16.0 * static_cast<double>(sl->n_ent[k]) / 3.5e9 + 0.008;
+}
+static double t_dense_step(const SparseLevels *sl, int s)
+{
+    const double a = sl->n_of[s], b = sl->n_of[s + 1];
+    return 4.0 * (a * a + b * b) / 4.6e9 + 0.008;
 }
 
 int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &err)
@@ -511,31 +593,68 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     if (sl->calibrated) return GENPHI_OK;
     sl->k = -1;
     if (sl->tun.force_k == -1) { sl->calibrated = true; return GENPHI_OK; }
-    int k = 0;
+    int last = 0;                                          // last cut whose lists exist
+    const bool trace = std::getenv("GENPHI_TRACE") != nullptr;
+    std::vector<unsigned> rnz;
+    std::vector<int> order;
+    int rc = launch_identity(sl, stream, err);
+    if (rc) return rc;
     for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be kept as lists only when step s+1 is eligible too
         if (sl->tun.force_k >= 0 && s + 1 > sl->tun.force_k) break;
-        const int rc = launch_step(sl, s, sl->cap_cal, stream, err);
+        const int n = sl->n_of[s + 1];
+        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, sl->n_ent[s] > 192ll * sl->n_of[s], stream, err);
         if (rc) return rc;
         unsigned st[4] = {0, 0, 0, 0};
+        rnz.resize(n);
         SP_TRY(hipMemcpyAsync(st, sl->stat + 4 * (s + 1), sizeof(st), hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipMemcpyAsync(rnz.data(), sl->rnz[s + 1], static_cast<size_t>(n) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         SP_TRY(hipStreamSynchronize(stream));
-        const double n = static_cast<double>(sl->n_of[s + 1]);
-        const bool ovf = st[2] != 0;
-        sl->nnz[s + 1] = ovf ? -1 : static_cast<long long>(st[3]);
-        sl->n_ent[s + 1] = ovf ? -1 : static_cast<long long>(st[0]);
+        if (st[2] != 0) break;                             // a row or the arena overflowed: too dense for lists
+        sl->nnz[s + 1] = static_cast<long long>(st[3]);
+        sl->n_ent[s + 1] = static_cast<long long>(st[0]);
         sl->max_row[s + 1] = static_cast<int>(st[1]);
-        if (ovf) break;
-        if (sl->tun.force_k < 0 && static_cast<double>(st[3]) > sl->tun.max_permille / 1000.0 * n * n) break;
-        k = s + 1;
+        // the rows of cut s+1 by length, longest first: a launch per class of lengths, each with the LDS its rows need
+        order.resize(n);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rnz[x] > rnz[y]; });
+        std::array<int, 4> &cl = sl->cls[s + 1];
+        cl = {0, 0, 0, n};
+        for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; if (rnz[order[q]] > 256u) cl[2] = q + 1; }
+        SP_TRY(hipMemcpyAsync(sl->order[s + 1], order.data(), static_cast<size_t>(n) * sizeof(int), hipMemcpyHostToDevice, stream));
+        SP_TRY(hipStreamSynchronize(stream));
+        last = s + 1;
+        const double dn = static_cast<double>(n);
+        if (trace)
+            std::fprintf(stderr, "[genphi trace]   sparse cut %2d: %6d members, %10lld non-zero (%.4f), %10lld list entries, longest row %5d, rows > 1024 / > 256: %d / %d; "
+                         "est. list step %.3f ms, dense step %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
+                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s));
+        if (sl->tun.force_k < 0) {
+            if (static_cast<double>(st[3]) > sl->tun.max_permille / 1000.0 * dn * dn) break;
+            if (t_list_step(sl, s) > 2.0 * t_dense_step(sl, s) + 0.02) break;     // (it only gets denser)
+        }
     }
     sl->calibrated = true;                                 // (from here on rows go where this run put them)
-    if (k < 1) return GENPHI_OK;
+    if (last < 1) return GENPHI_OK;
+    int k = last;
     if (sl->tun.force_k < 0) {
+        // the last sparse cut: the cheapest of "lists up to cut k, the dense matrix of cut k+1 from them, dense beyond"
+        double best = 0.0;
+        for (int s = 0; s <= last; ++s) best += t_dense_step(sl, s);
+        k = -1;
+        double lists = 0.0;                                // steps 0..k-1 as list steps
+        for (int kk = 1; kk <= last; ++kk) {
+            lists += t_list_step(sl, kk - 1);
+            double t = lists + t_dense_from_lists(sl, kk);
+            for (int s = kk + 1; s <= last; ++s) t += t_dense_step(sl, s);
+            if (t < best) { best = t; k = kk; }
+        }
+        if (k < 1) return GENPHI_OK;
         int widest = 0;
         for (int c = 0; c <= k + 1; ++c) widest = std::max(widest, sl->n_of[c]);
         if (widest < sl->tun.min_cut) return GENPHI_OK;
     }
     sl->k = k;
+    if (trace) std::fprintf(stderr, "[genphi trace]   sparse cuts 0..%d\n", k);
     return GENPHI_OK;
 }
 
@@ -544,8 +663,23 @@ int sparse_levels_k(const SparseLevels *sl) { return sl ? sl->k : -1; }
 int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std::string &err)
 {
     if (!sl || s < 0 || s >= sl->k) { err = "sparse_levels_enqueue_step: not a sparse step"; return GENPHI_ERR_ARG; }
-    const int cap = std::min(sl->cap_cal, std::max(64, (sl->max_row[s + 1] + 63) / 64 * 64));
-    return launch_step(sl, s, cap, stream, err);
+    int rc = s == 0 ? launch_identity(sl, stream, err) : GENPHI_OK;
+    if (rc) return rc;
+    const std::array<int, 4> &cl = sl->cls[s + 1];
+    const int *ord = sl->order[s + 1];
+    const int cap_max = std::min(sl->cap_cal, std::max(64, (sl->max_row[s + 1] + 63) / 64 * 64));
+    // One launch for all rows when their lengths are alike (random mating: the longest row of a cut is less than twice the average) --
+    // several launches cost their tails (cfg4: +12 % on its two largest list steps) -- and a launch per class of lengths when they are
+    // not (a real genealogy: the longest row of genea140's cut 8 is 12 x the average; -11 % over its list steps).  classes = 1 / 0 force.
+    const bool skewed = static_cast<long long>(sl->max_row[s + 1]) * sl->n_of[s + 1] > 3ll * sl->nnz[s + 1];
+    if (sl->tun.classes == 0 || (sl->tun.classes < 0 && !skewed))
+        return launch_rows(sl, s, nullptr, sl->n_of[s + 1], cap_max, sl->n_ent[s] > 192ll * sl->n_of[s], stream, err);
+    // rows of more than 1024 entries, of more than 256, the rest: each launch with the LDS its rows need (a launch sized for the
+    // longest row of a real genealogy leaves room for four wavefronts per CU)
+    rc = launch_rows(sl, s, ord + cl[0], cl[1] - cl[0], cap_max, true, stream, err);
+    if (rc == GENPHI_OK) rc = launch_rows(sl, s, ord + cl[1], cl[2] - cl[1], std::min(cap_max, 1024), true, stream, err);
+    if (rc == GENPHI_OK) rc = launch_rows(sl, s, ord + cl[2], cl[3] - cl[2], std::min(cap_max, 256), false, stream, err);
+    return rc;
 }
 
 int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long long width, hipStream_t stream, std::string &err)

@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP", "GENPHI_FAST_NT", "GENPHI_NO_FAST",
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
-         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE", "GENPHI_SPARSE_NO_FUSED"]
+         "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE", "GENPHI_SPARSE_NO_FUSED",
+         "GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_CHUNK"]
 
 
 def make_case(case):
@@ -86,6 +87,20 @@ def make_case(case):
         env["GENPHI_STAY_SCALAR_T"] = "1"                                         # the fused in-place kernel's transposed tile by 4-byte stores
     if r.random() < 0.3:
         env["GENPHI_SPARSE_NO_FUSED"] = "1"                                       # sparse_phi: a wave as rows + new x new kernels with T in HBM
+    # (round 5) the leading cuts as lists of their non-zero entries (csrc/sparse_levels.hip): forced on small pedigrees, any last sparse
+    # cut, the launch forms of a list step, small chunks of the sparse -> dense step.  Drawn from a generator of their own: the cases of
+    # earlier rounds keep their pedigrees and knobs.
+    r5 = np.random.default_rng([case, 5])
+    if r5.random() < 0.7:
+        env["GENPHI_SPARSE_MIN_CUT"] = "0"
+        if r5.random() < 0.7:
+            env["GENPHI_SPARSE_K"] = str(int(r5.choice([1, 2, 3, 5, 8, 11])))
+        if r5.random() < 0.5:
+            env["GENPHI_SPARSE_CLASSES"] = str(int(r5.choice([0, 1])))
+        if r5.random() < 0.4:
+            env["GENPHI_SPARSE_CHUNK"] = str(int(r5.choice([1024, 2048])))
+    elif r5.random() < 0.3:
+        env["GENPHI_SPARSE_K"] = "-1"
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env
 
 
@@ -97,7 +112,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed0)
-    t0, n_cases, n_fail, n_stay = time.time(), 0, 0, 0
+    t0, n_cases, n_fail, n_stay, n_sparse = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         case = int(rng.integers(1 << 30))
         r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env = make_case(case)
@@ -118,6 +133,9 @@ def main():
             n_stay += sum(pl.step_slots(k)[0] & 1 for k in range(len(pl.step_modes())))
             if not np.array_equal(pl.compute(), want):
                 what.append("full")
+            n_sparse += pl.sparse_levels()[0] + 1
+            if pl.sparse_levels()[0] >= 1 and not np.array_equal(pl.compute(no_sparse=True), want):
+                what.append("same-plan-dense")
             if n > 2:
                 a = int(r.integers(0, n - 1)); b = int(r.integers(a + 1, n + 1))
                 if not np.array_equal(pl.compute(rows=(a, b)), want[a:b]):
@@ -148,7 +166,7 @@ def main():
             print(f"FAIL case={case} gens={n_gen} n_ind={n_ind} n_pro={n_pro} skip={skip} env={env} -> {what}", flush=True)
         if n_cases % 20 == 0:
             print(f"... {n_cases} cases, {n_fail} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"stress: {n_cases} cases ({n_stay} in-place steps among them), {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
+    print(f"stress: {n_cases} cases ({n_stay} in-place steps and {n_sparse} sparse cuts among them), {n_fail} failures in {time.time() - t0:.0f} s (seed {seed0})", flush=True)
     return 1 if n_fail else 0
 
 

@@ -1539,10 +1539,14 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
         assert pl.sparse_levels()[0] == {"1": 1, "4": 4, "9": 9, "11": 10, "-1": -1}[force], pl.sparse_levels()      # (cut 11 is the last one exact in integer units)
         pl.close()
     monkeypatch.delenv("GENPHI_SPARSE_K", raising=False)
-    # small chunks of the sparse -> dense step: rows of several workgroups
+    # small chunks of the sparse -> dense step: rows of several workgroups; a list step as one launch / as a launch per class of row lengths
     monkeypatch.setenv("GENPHI_SPARSE_CHUNK", "1024")
     _assert_equal(gen.phi(ped), gold)
     monkeypatch.delenv("GENPHI_SPARSE_CHUNK", raising=False)
+    for v in ("0", "1"):
+        monkeypatch.setenv("GENPHI_SPARSE_CLASSES", v)
+        _assert_equal(gen.phi(ped), gold)
+    monkeypatch.delenv("GENPHI_SPARSE_CLASSES", raising=False)
     # random mating (every row of every cut new, no dragged members) and overlapping generations, by calibration
     for args, kw in (((30000, 3000, 10), dict(skip_permille=0)), ((30000, 2000, 14), dict(skip_permille=30))):
         ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
