@@ -19,6 +19,7 @@ All kinship arithmetic runs in hand-written HIP kernels behind the C-ABI in
 include/genphi.h (csrc/genphi_hip.hip); there is no CPU fallback.
 """
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -68,11 +69,12 @@ class Pedigree:
     """
 
     def __init__(self, ind, father, mother, sex):
-        self.ind = np.ascontiguousarray(ind, dtype=np.int64)
-        self.father = np.ascontiguousarray(father, dtype=np.int64)
-        self.mother = np.ascontiguousarray(mother, dtype=np.int64)
-        self.sex = np.ascontiguousarray(sex, dtype=np.int64)
+        # (read-only, like the reference's immutable Individual structs, src/create.jl:39-46: gen.phi keeps plans per pedigree)
+        self.ind, self.father, self.mother, self.sex = (np.array(a, dtype=np.int64, order="C") for a in (ind, father, mother, sex))
+        for a in (self.ind, self.father, self.mother, self.sex):
+            a.setflags(write=False)
         self._index = None
+        self._plans = OrderedDict()          # gen.phi's plans for this pedigree, least recently used first (see _plan_for)
 
     def __len__(self):
         return len(self.ind)
@@ -162,6 +164,44 @@ def plan(pedigree, probandIDs=None):
     return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs)
 
 
+# gen.phi keeps the plans of its last calls per pedigree: the host prologue of the reference's phi (src/compute.jl:236-262:
+# levelisation, cut sets, index copy) depends on (pedigree, probandIDs) alone, so a repeated call -- another subset, then the first one
+# again; a parameter sweep -- skips planning, upload and the calibration of the sparse levels and pays the sweep and the copy.
+PLAN_CACHE_ENTRIES = 4                 # per pedigree; 0 disables (also GENPHI_PLAN_CACHE=0)
+PLAN_CACHE_DEVICE_BYTES = 2 << 30      # a plan that holds more device memory than this is released at the end of its call
+
+
+def _plan_for(pedigree, probandIDs, device):
+    """(plan, keep): the cached plan of this call, or a new one."""
+    probandIDs = pro(pedigree) if probandIDs is None else np.ascontiguousarray(probandIDs, dtype=np.int64)
+    entries = 0 if os.environ.get("GENPHI_PLAN_CACHE") == "0" else PLAN_CACHE_ENTRIES
+    cache = getattr(pedigree, "_plans", None)
+    if entries <= 0 or cache is None:
+        return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs), None
+    # (the library reads its GENPHI_* hooks when a plan is created: a plan made under other settings is another plan)
+    key = (hash(probandIDs.tobytes()), len(probandIDs), device, tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("GENPHI_"))))
+    hit = cache.get(key)
+    if hit is not None and np.array_equal(hit[1], probandIDs):
+        cache.move_to_end(key)
+        return hit[0], key
+    return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs), key
+
+
+def _keep_plan(pedigree, key, pl, probandIDs):
+    cache = pedigree._plans
+    if key in cache and cache[key][0] is pl:
+        return True
+    if pl.device_bytes > PLAN_CACHE_DEVICE_BYTES:
+        return False
+    old = cache.pop(key, None)
+    if old is not None:
+        old[0].close()
+    cache[key] = (pl, np.array(probandIDs, dtype=np.int64))
+    while len(cache) > PLAN_CACHE_ENTRIES:
+        cache.popitem(last=False)[1][0].close()
+    return True
+
+
 def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, kernel=0):
     """gen.phi(pedigree, probandIDs = pro(pedigree); verbose=false, compute=true), or the pairwise
     method gen.phi(individual_i, individual_j) (src/compute.jl:66-95) when called with two
@@ -181,11 +221,13 @@ def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, ker
             raise TypeError("gen.phi(individual_i, individual_j) takes two individuals of one pedigree")
         ped = a.pedigree
         return float(_capi.phi_pairs(ped.ind, ped.father, ped.mother, [a.ID], [b.ID], device=device)[0])
-    pl = plan(pedigree, probandIDs)
+    probandIDs = pro(pedigree) if probandIDs is None else np.ascontiguousarray(probandIDs, dtype=np.int64)
+    pl, key = _plan_for(pedigree, probandIDs, device)
+    keep = False
     try:
-        sizes, both = pl.levels()
-        nsteps = max(len(sizes) - 1, 0)
         if verbose or not compute:
+            sizes, both = pl.levels()
+            nsteps = max(len(sizes) - 1, 0)
             for i in range(nsteps):
                 print(f"Step {i + 1} of {nsteps}: {sizes[i]} founders, {sizes[i + 1]} probands, {both[i]} both.")
         if not compute:
@@ -194,9 +236,18 @@ def phi(pedigree, probandIDs=None, verbose=False, compute=True, device=None, ker
             # the reference prints these inside its level loop (src/compute.jl:280-285): the library calls back right before it
             # hands each level step to the GPU
             pl.set_step_hook(lambda k, n: print(f"Running step {k + 1} of {n} ({sizes[k]} founders, {sizes[k + 1]} probands, {both[k]} both).", flush=True))
-        return pl.compute(device=device, kernel=kernel)
+        try:
+            out = pl.compute(device=device, kernel=kernel)
+        finally:
+            if verbose:
+                pl.set_step_hook(None)               # (a hook left set would keep the plan off its captured graph)
+        keep = key is not None and _keep_plan(pedigree, key, pl, probandIDs)
+        return out
     finally:
-        pl.close()
+        if not keep:
+            if key is not None and key in pedigree._plans and pedigree._plans[key][0] is pl:
+                del pedigree._plans[key]             # (a cached plan whose call failed)
+            pl.close()
 
 
 def f(pedigree, IDs, device=None):

@@ -45,10 +45,10 @@ class GenphiStats(C.Structure):
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
     "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
-    "genphi_plan_algorithmic_bytes", "genphi_plan_sparse_levels", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
+    "genphi_plan_algorithmic_bytes", "genphi_plan_device_bytes", "genphi_plan_sparse_levels", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
-    "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_plan_release_device", "genphi_plan_destroy",
+    "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_release_cached", "genphi_cached_bytes", "genphi_plan_release_device", "genphi_plan_destroy",
     "genphi_last_error",
     "genphi_version", "genphi_sparse_phi", "genphi_sparse_info", "genphi_sparse_stats", "genphi_sparse_schedule", "genphi_genealogy_order", "genphi_sparse_get", "genphi_sparse_entries", "genphi_sparse_destroy",
     "genphi_panel_create", "genphi_panel_step_mode", "genphi_panel_step_ms", "genphi_panel_n_steps", "genphi_panel_n_probands", "genphi_panel_result_rows", "genphi_panel_exchange_counts",
@@ -94,6 +94,12 @@ def lib():
         L.genphi_plan_step_walk.restype = C.c_int
         L.genphi_plan_set_step_hook.argtypes = [C.c_void_p, STEP_FN, C.c_void_p]
         L.genphi_plan_set_step_hook.restype = C.c_int
+        L.genphi_plan_device_bytes.argtypes = [C.c_void_p]
+        L.genphi_plan_device_bytes.restype = C.c_int64
+        L.genphi_release_cached.argtypes = []
+        L.genphi_release_cached.restype = None
+        L.genphi_cached_bytes.argtypes = []
+        L.genphi_cached_bytes.restype = C.c_int64
         L.genphi_plan_sparse_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _I64P, C.c_int32]
         L.genphi_plan_sparse_levels.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
@@ -201,6 +207,15 @@ def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
 
+def release_cached():
+    """Give back what the library keeps between calls (device blocks of released plans, idle streams, pinned staging): genphi_release_cached."""
+    lib().genphi_release_cached()
+
+
+def cached_bytes():
+    return int(lib().genphi_cached_bytes())
+
+
 def genealogy_read(path, sort=True):
     """(ind, father, mother, sex) int64 arrays in rank order, parsed and depth-sorted natively."""
     L = lib()
@@ -299,6 +314,11 @@ class PhiPlan:
     @property
     def n_probands(self):
         return int(lib().genphi_plan_n_probands(self._h))
+
+    @property
+    def device_bytes(self):
+        """Device memory the plan holds right now (index arrays, level matrices, row lists, the resident result)."""
+        return int(lib().genphi_plan_device_bytes(self._h))
 
     @property
     def algorithmic_bytes(self):

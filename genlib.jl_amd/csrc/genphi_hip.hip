@@ -53,6 +53,7 @@
 
 #include "../../include/genphi.h"
 #include "panel_launch.h"
+#include "devcache.h"
 #include "planner.h"
 #include "sparse_levels.h"
 
@@ -1943,20 +1944,7 @@ static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 
-// GENPHI_TRACE=1: wall-clock marks of the phases of a compute call on stderr (where does a first call go?)
-struct PhaseTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t0, last;
-    PhaseTrace() : on(std::getenv("GENPHI_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), last(t0) {}
-    void mark(const char *what)
-    {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[genphi trace] %-28s +%8.3f ms  (at %8.3f ms)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
-                     std::chrono::duration<double, std::milli>(now - t0).count());
-        last = now;
-    }
-};
+using genphi::PhaseTrace;      // GENPHI_TRACE=1: wall-clock marks of the phases of a call on stderr (planner.h)
 int genphi_set_error(int code, const std::string &msg) { return fail(code, msg); }   // for loader.cpp
 
 #define HIP_TRY(expr)                                                                           \
@@ -2156,6 +2144,9 @@ struct genphi_plan {
     int n_cus = 256;
     hipStream_t stream = nullptr;
     char *idx_blob = nullptr;
+    std::vector<char *> lazy_blobs;              // walk lists uploaded after the index blob (ensure_groups)
+    size_t lazy_bytes = 0;
+    size_t idx_blob_bytes = 0, psi_p_floats = 0, nn_tmp_floats = 0;      // (genphi_plan_device_bytes)
     std::vector<DeviceStep> dsteps;
     std::vector<const LevelStep *> nn_steps;     // new x new sub-steps of the WIDE steps (owned by the plan's steps)
     std::vector<DeviceStep> nn_dsteps;
@@ -2221,9 +2212,6 @@ struct genphi_plan {
     genphi::SparseLevels *sparse = nullptr;
     bool sparse_tried = false;
     std::vector<hipEvent_t> events;
-    std::vector<void *> pin;                // pinned staging chunks of genphi_result_to_host (2 per worker)
-    std::vector<hipStream_t> pin_streams;
-    size_t pin_bytes = 0;
 };
 
 static void drop_graph(genphi_plan *p)
@@ -2245,8 +2233,10 @@ static void free_device(genphi_plan *p)
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     p->events.clear();
     drop_graph(p);
-    auto release = [](auto *&ptr) { if (ptr) (void)hipFree(ptr); ptr = nullptr; };
-    release(p->idx_blob);
+    auto release = [](auto *&ptr) { if (ptr) (void)genphi::cached_free(ptr); ptr = nullptr; };
+    release(p->idx_blob); p->idx_blob_bytes = 0; p->psi_p_floats = p->nn_tmp_floats = 0;
+    for (char *&b : p->lazy_blobs) release(b);
+    p->lazy_blobs.clear(); p->lazy_bytes = 0;
     release(p->d_shard_rows); release(p->d_shard_out_rows); release(p->d_shard_blob);
     release(p->d_glist); p->d_cert = p->d_gcnt = nullptr; p->sweep_words = 0;      // (d_cert / d_gcnt live inside d_queues' array)
     p->shard_groups = DeviceGroups(); p->shard_blob_bytes = 0; p->cert_off.clear(); p->cert_words = 0;
@@ -2265,10 +2255,7 @@ static void free_device(genphi_plan *p)
     p->buf_floats[0] = p->buf_floats[1] = 0; p->level_bufs_ready = false;
     p->result_floats = p->final_tmp_floats = 0; p->scratch_bytes = 0;
     p->res_ld = 0; p->res_row_begin = 0; p->res_n_rows = 0;
-    for (void *q : p->pin) (void)hipHostFree(q);
-    for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
-    p->pin.clear(); p->pin_streams.clear(); p->pin_bytes = 0;
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    genphi::cached_stream_release(p->stream, p->device);
     p->stream = nullptr;
     p->on_device = false;
     p->device = -1;
@@ -2359,6 +2346,17 @@ int genphi_plan_step_slots(const genphi_plan *plan, int32_t step, int64_t *info)
     return GENPHI_OK;
 }
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan) { return plan ? plan->plan.algorithmic_bytes : 0.0; }
+int64_t genphi_plan_device_bytes(const genphi_plan *p)
+{
+    if (!p || !p->on_device) return 0;
+    const double b = static_cast<double>(p->idx_blob_bytes) + static_cast<double>(p->lazy_bytes) + static_cast<double>(p->shard_blob_bytes) + static_cast<double>(p->scratch_bytes) +
+                     4.0 * (static_cast<double>(p->buf_floats[0]) + static_cast<double>(p->buf_floats[1]) + static_cast<double>(p->result_floats) +
+                            static_cast<double>(p->final_tmp_floats) + static_cast<double>(p->psi_p_floats) + static_cast<double>(p->nn_tmp_floats) +
+                            static_cast<double>(p->sweep_words)) +
+                     8.0 * (static_cast<double>(p->buf64_doubles[0]) + static_cast<double>(p->buf64_doubles[1]) + static_cast<double>(p->result64_doubles)) +
+                     genphi::sparse_levels_device_bytes(p->sparse);
+    return static_cast<int64_t>(b);
+}
 int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap)
 {
     if (k_out) *k_out = -1;
@@ -2394,6 +2392,13 @@ int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows
     return GENPHI_OK;
 }
 
+void genphi_release_cached(void)
+{
+    genphi::sparse_phi_release_kept();
+    genphi::release_cached();
+}
+int64_t genphi_cached_bytes(void) { return static_cast<int64_t>(genphi::cached_bytes()); }
+
 int genphi_plan_release_device(genphi_plan *plan)
 {
     if (!plan) return fail(GENPHI_ERR_ARG, "plan is NULL");
@@ -2414,7 +2419,7 @@ void genphi_plan_destroy(genphi_plan *plan)
 static hipError_t plan_malloc(genphi_plan *p, void **ptr, size_t bytes)
 {
     if (p->tun.fail_alloc_at > 0 && ++p->alloc_count == p->tun.fail_alloc_at) return hipErrorOutOfMemory;
-    return hipMalloc(ptr, bytes);
+    return genphi::cached_malloc(ptr, bytes);
 }
 
 // upload the flat index arrays once
@@ -2433,11 +2438,11 @@ static int upload_plan_impl(genphi_plan *p, int device)
     HIP_TRY(hipSetDevice(device));
     p->device = device;
     p->on_device = true;                              // (free_device releases whatever exists; upload_plan calls it on any failure below)
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(genphi::cached_stream(&p->stream));
     {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
+        int cus = 0;                                  // (hipGetDeviceProperties fills a 1.5 KB struct from dozens of queries: tens of ms of a first call)
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        p->n_cus = std::max(8, cus / 8 * 8);
     }
 
     trace.mark("  upload: device, stream");
@@ -2452,8 +2457,11 @@ static int upload_plan_impl(genphi_plan *p, int device)
     auto step_at = [&](size_t k) -> const LevelStep & { return k < n_main ? pl.steps[k] : *p->nn_steps[k - n_main]; };
     std::vector<GroupLists> step_groups(n_all);
     {   // the hub walks of the SPLIT steps are independent of each other: a few host threads (24 -> ~7 ms of a first call on cfg4)
+        // (the leading steps that may run on row lists -- sparse_levels.h -- get their walk lists when a sweep first runs them densely:
+        // ensure_groups; genea140: five of its SPLIT steps, 1-2 ms of every one-shot call, never do)
+        const size_t lazy_upto = (p->tun.sparse_k == -1 || p->popt.indices_only) ? 0 : static_cast<size_t>(genphi::sparse_eligible_steps(pl));
         std::vector<size_t> split_steps;
-        for (size_t k = 0; k < n_all; ++k) if (step_at(k).mode == genphi::kModeSplit) split_steps.push_back(k);
+        for (size_t k = 0; k < n_all; ++k) if (step_at(k).mode == genphi::kModeSplit && !(k < n_main && k < lazy_upto)) split_steps.push_back(k);
         std::sort(split_steps.begin(), split_steps.end(), [&](size_t a, size_t b) { return step_at(a).n > step_at(b).n; });      // the big last step first
         const int n_thr = static_cast<int>(std::min<size_t>(4, split_steps.size()));
         std::atomic<size_t> next{0};
@@ -2477,7 +2485,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
     for (size_t k = 0; k < n_all; ++k) {
         const LevelStep &s = step_at(k);
         total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
-        if (s.mode == genphi::kModeSplit) total += groups_bytes(step_groups[k]);
+        if (s.mode == genphi::kModeSplit && !step_groups[k].w.run.empty()) total += groups_bytes(step_groups[k]);
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
                      al((s.n - s.n_dragged) * sizeof(int)) + al((s.n_dragged / 8192 + 2) * sizeof(int)) + al(s.n_dragged * sizeof(int)) +
@@ -2486,6 +2494,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
     total += al(pl.final_perm.size() * sizeof(int)) + al(pl.final_slots.size() * sizeof(int));
     trace.mark("  upload: walk lists (host)");
     HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->idx_blob), total));
+    p->idx_blob_bytes = total;
     trace.mark("  upload: hipMalloc index blob");
     std::vector<char> host(total, 0);
     size_t off = 0;
@@ -2511,7 +2520,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
             const unsigned zero_pk = static_cast<unsigned>(s.n_prev) | (static_cast<unsigned>(s.n_prev) << 16);
             for (size_t k2 = s.pk.size(); k2 < s.pk.size() + kIdxPad; ++k2) hp[k2] = zero_pk;
         }
-        if (s.mode == genphi::kModeSplit) put_groups(step_groups[k], d.groups, put);
+        if (s.mode == genphi::kModeSplit && !step_groups[k].w.run.empty()) put_groups(step_groups[k], d.groups, put);
         if (s.mode == genphi::kModeWide) {
             // (a source cut stored by slot: sources, parents and "none" are slots of its P x P matrix; a step that stays in
             // place writes row r of its cut to the member's slot)
@@ -2634,10 +2643,12 @@ static int ensure_level_buffers_impl(genphi_plan *p)
         if (need_t) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->nn_tmp), (need_t * need_t + kTailPadFloats) * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->nn_tmp, 0, (need_t * need_t + kTailPadFloats) * sizeof(float), p->stream));
+            p->nn_tmp_floats = need_t * need_t + kTailPadFloats;
         }
         if (need_p) {
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->psi_p), need_p * sizeof(float)));
             HIP_TRY(hipMemsetAsync(p->psi_p, 0, need_p * sizeof(float), p->stream));
+            p->psi_p_floats = need_p;
         }
         if (need_p || need_t) {                                    // (one array: an in-place step clears both in one launch)
             HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&p->d_cert_p), (need_c + need_t + 1) * sizeof(int)));
@@ -2678,8 +2689,8 @@ static int ensure_floats(genphi_plan *p, float **ptr, size_t *have, size_t need)
 {
     if (*have >= need && *ptr) return GENPHI_OK;
     drop_graph(p);                                   // a captured sweep points at the old buffer
-    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(float)));
+    if (*ptr) { HIP_TRY(genphi::cached_free(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(float)));
     *have = need;
     return GENPHI_OK;
 }
@@ -2687,9 +2698,9 @@ static int ensure_floats(genphi_plan *p, float **ptr, size_t *have, size_t need)
 static int ensure_scratch(genphi_plan *p, size_t bytes)
 {
     if (p->scratch_bytes >= bytes && p->scratch) return GENPHI_OK;
-    if (p->scratch) { HIP_TRY(hipFree(p->scratch)); p->scratch = nullptr; p->scratch_bytes = 0; }
+    if (p->scratch) { HIP_TRY(genphi::cached_free(p->scratch)); p->scratch = nullptr; p->scratch_bytes = 0; }
     const size_t want = std::max<size_t>(bytes, size_t(1) << 16);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->scratch), want));
+    HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->scratch), want));
     p->scratch_bytes = want;
     return GENPHI_OK;
 }
@@ -2846,6 +2857,34 @@ static LevelCtx main_ctx(genphi_plan *p, int step)
     c.no_none_row = false;
     c.dbg = (p->tun.dbg_step >= 0 ? p->tun.dbg_step : static_cast<int>(p->plan.steps.size()) - 1) == step;     // default: the last step
     return c;
+}
+
+// Walk lists of a SPLIT step that the upload left out (a leading step that may run on row lists): built and uploaded when a sweep first
+// runs the step densely.
+static int ensure_groups(genphi_plan *p, int step)
+{
+    const LevelStep &s = p->plan.steps[step];
+    DeviceStep &d = p->dsteps[step];
+    if (s.mode != genphi::kModeSplit || d.groups.desc != nullptr) return GENPHI_OK;
+    GroupLists gl;
+    build_groups(s, s.work.data(), nullptr, static_cast<int>(s.work.size()), gl, p->tun);
+    const size_t gb = groups_bytes(gl);
+    char *blob = nullptr;
+    HIP_TRY(plan_malloc(p, reinterpret_cast<void **>(&blob), gb));
+    p->lazy_blobs.push_back(blob);
+    p->lazy_bytes += gb;
+    std::vector<char> img(gb, 0);
+    size_t off = 0;
+    auto put = [&](const void *src, size_t bytes) -> char * {
+        char *dst = blob + off;
+        if (bytes) std::memcpy(img.data() + off, src, bytes);
+        off += al256(bytes);
+        return dst;
+    };
+    put_groups(gl, d.groups, put);
+    HIP_TRY(hipMemcpyAsync(blob, img.data(), gb, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));          // `img` goes out of scope
+    return GENPHI_OK;
 }
 
 // What a FULL / SPLIT launch needs from its owner (a plan's level step, or a rank's column panel)
@@ -3228,8 +3267,8 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
 static int ensure_doubles(double **ptr, size_t *have, size_t need)
 {
     if (*have >= need && *ptr) return GENPHI_OK;
-    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(double)));
+    if (*ptr) { HIP_TRY(genphi::cached_free(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(ptr), std::max<size_t>(need, 1) * sizeof(double)));
     *have = need;
     return GENPHI_OK;
 }
@@ -3251,8 +3290,8 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
     std::vector<int> srow(n_rows), orow(n_rows);
     for (int64_t k = 0; k < n_rows; ++k) { srow[k] = pl.final_perm.empty() ? static_cast<int>(r0 + k) : pl.final_perm[r0 + k]; orow[k] = static_cast<int>(k); }
     if (static_cast<size_t>(2 * n_rows) > p->perm_rows_cap) {
-        if (p->d_perm_rows) { HIP_TRY(hipFree(p->d_perm_rows)); p->d_perm_rows = nullptr; }
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_perm_rows), 2 * n_rows * sizeof(int)));
+        if (p->d_perm_rows) { HIP_TRY(genphi::cached_free(p->d_perm_rows)); p->d_perm_rows = nullptr; }
+        HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->d_perm_rows), 2 * n_rows * sizeof(int)));
         p->perm_rows_cap = static_cast<size_t>(2 * n_rows);
     }
     HIP_TRY(hipMemcpyAsync(p->d_perm_rows, srow.data(), n_rows * sizeof(int), hipMemcpyHostToDevice, p->stream));
@@ -3432,10 +3471,10 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     // shard row lists for the last step: storage row of proband r, output row r - r0
     if (n_rows > p->shard_cap) {
         drop_graph(p);
-        if (p->d_shard_rows) { HIP_TRY(hipFree(p->d_shard_rows)); HIP_TRY(hipFree(p->d_shard_out_rows)); }
+        if (p->d_shard_rows) { HIP_TRY(genphi::cached_free(p->d_shard_rows)); HIP_TRY(genphi::cached_free(p->d_shard_out_rows)); }
         p->d_shard_rows = p->d_shard_out_rows = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_rows), n_rows * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
+        HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->d_shard_rows), n_rows * sizeof(int)));
+        HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
@@ -3468,8 +3507,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
             build_groups(pl.steps[n_steps - 1], rows.data(), orows.data(), static_cast<int>(n_rows), gl, p->tun);
             const size_t gb = groups_bytes(gl);
             if (gb > p->shard_blob_bytes) {
-                if (p->d_shard_blob) { HIP_TRY(hipFree(p->d_shard_blob)); p->d_shard_blob = nullptr; p->shard_blob_bytes = 0; }
-                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_shard_blob), gb));
+                if (p->d_shard_blob) { HIP_TRY(genphi::cached_free(p->d_shard_blob)); p->d_shard_blob = nullptr; p->shard_blob_bytes = 0; }
+                HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->d_shard_blob), gb));
                 p->shard_blob_bytes = gb;
             }
             gimg.assign(gb, 0);
@@ -3487,7 +3526,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         p->shard_r0 = r0; p->shard_r1 = r1;
 
         // upper levels restricted to the ancestors of the shard (walk the sources backwards)
-        (void)hipFree(p->sh_blob); p->sh_blob = nullptr; p->sh_valid = false;
+        (void)genphi::cached_free(p->sh_blob); p->sh_blob = nullptr; p->sh_valid = false;
         p->sh_steps.assign(std::max(n_steps, 1), genphi_plan::ShardStep());
         const bool sharded = n_rows < pl.n_pro && n_steps >= 2 && !p->tun.no_shard_prune;
         if (sharded) {
@@ -3529,7 +3568,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                 total += al(rw.size() * sizeof(int));
                 need.swap(need_prev);
             }
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->sh_blob), total));
+            HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->sh_blob), total));
             std::vector<char> host(total, 0);
             size_t off = 0;
             auto put = [&](const void *src, size_t bytes) -> char * {
@@ -3627,9 +3666,12 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     else if (p->sh_valid && p->sh_steps[s].rows && s >= prune_min_step)
                         rc = launch_level(p, main_ctx(p, s), psi, out, p->sh_steps[s].rows, nullptr, p->sh_steps[s].n_rows, kernel,
                                           p->sh_steps[s].groups);
-                    else
-                        rc = launch_level(p, main_ctx(p, s), psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
-                                          p->dsteps[s].groups);
+                    else {
+                        rc = ensure_groups(p, s);
+                        if (rc == GENPHI_OK)
+                            rc = launch_level(p, main_ctx(p, s), psi, out, p->dsteps[s].work, nullptr, static_cast<int>(st.n), kernel,
+                                              p->dsteps[s].groups);
+                    }
                     if (rc) return rc;
                     // the all-zero "none" row of this level (FULL / SPLIT / WIDE launches write it themselves)
                     if (kernel == 1 && st.mode != genphi::kModeWide)
@@ -3835,8 +3877,8 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     // the lot.  On a host with cores to spare it is the faster path; here it is not reliably so, hence not the default.
     bool sym = rows == N && p->res_row_begin == 0 && N >= 2 && !p->tun.d2h_pageable && p->tun.d2h_sym == 1;
     int n_thr = 1;
-    if (bytes >= (size_t(256) << 20) || sym) {
-        n_thr = sym ? 16 : 8;
+    if (bytes >= (size_t(64) << 20) || sym) {              // (one worker per 32 MB up to 8: the ring is kept between calls, so mid-size results use it too)
+        n_thr = sym ? 16 : static_cast<int>(std::min<size_t>(8, bytes >> 25));
         if (p->tun.d2h_threads > 0) n_thr = std::max(1, std::min(32, p->tun.d2h_threads));
     }
     const size_t row_bytes = N * sizeof(float);
@@ -3845,25 +3887,17 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     const size_t chunk_rows = std::max<size_t>(1, (size_t(16) << 20) / row_bytes);
     const size_t chunk_bytes = sym ? std::max<size_t>(tile_r * std::min(tile_c, N) * sizeof(float), 4096) : chunk_rows * row_bytes;
     bool pinned = (n_thr > 1 || sym) && !p->tun.d2h_pageable;
-    if (pinned && (p->pin.size() < static_cast<size_t>(2 * n_thr) || p->pin_bytes < chunk_bytes)) {
-        for (void *q : p->pin) (void)hipHostFree(q);
-        for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
-        p->pin.clear(); p->pin_streams.clear(); p->pin_bytes = 0;
-        for (int k = 0; k < 2 * n_thr && pinned; ++k) {
-            void *q = nullptr;
-            if (hipHostMalloc(&q, chunk_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = false; break; }
-            p->pin.push_back(q);
-        }
-        for (int k = 0; k < n_thr && pinned; ++k) {
-            hipStream_t st = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pinned = false; break; }
-            p->pin_streams.push_back(st);
-        }
-        if (pinned) p->pin_bytes = chunk_bytes;
-        else {                                          // could not pin: fall back to direct copies
-            for (void *q : p->pin) (void)hipHostFree(q);
-            for (hipStream_t st : p->pin_streams) (void)hipStreamDestroy(st);
-            p->pin.clear(); p->pin_streams.clear();
+    // (the ring belongs to the device, not to the plan: pinning 256 MB costs 60-100 ms and unpinning them 80 ms -- per one-shot call
+    // when every plan had its own; devcache.h)
+    genphi::PinnedRing *ring = nullptr;
+    std::unique_lock<std::mutex> ring_lock;
+    if (pinned) {
+        ring = &genphi::pinned_ring(p->device);
+        ring_lock = std::unique_lock<std::mutex>(ring->mu);
+        if (!genphi::pinned_ring_reserve(*ring, static_cast<size_t>(2 * n_thr), chunk_bytes, static_cast<size_t>(n_thr))) {
+            pinned = false;                             // could not pin: fall back to direct copies
+            ring_lock.unlock();
+            ring = nullptr;
         }
     }
     if (!pinned) sym = false;
@@ -3885,8 +3919,8 @@ int genphi_result_to_host(genphi_plan *p, float *out)
         auto worker = [&](int t) {
             hipError_t e = hipSetDevice(p->device);
             if (e != hipSuccess) { errs[t] = e; return; }
-            hipStream_t st = p->pin_streams[t];
-            float *pb[2] = {static_cast<float *>(p->pin[2 * t]), static_cast<float *>(p->pin[2 * t + 1])};
+            hipStream_t st = ring->stream[t];
+            float *pb[2] = {static_cast<float *>(ring->chunk[2 * t]), static_cast<float *>(ring->chunk[2 * t + 1])};
             auto issue = [&](const Item &it, float *dst) {
                 const size_t w = it.c1 - it.cs;
                 return hipMemcpy2DAsync(dst, w * sizeof(float), p->result + static_cast<size_t>(it.a) * static_cast<size_t>(p->res_ld) + it.cs, src_pitch,
@@ -3961,8 +3995,8 @@ int genphi_result_to_host(genphi_plan *p, float *out)
                                   row_bytes, r1 - r0, hipMemcpyDeviceToHost);
             return;
         }
-        hipStream_t st = p->pin_streams[t];
-        char *pb[2] = {static_cast<char *>(p->pin[2 * t]), static_cast<char *>(p->pin[2 * t + 1])};
+        hipStream_t st = ring->stream[t];
+        char *pb[2] = {static_cast<char *>(ring->chunk[2 * t]), static_cast<char *>(ring->chunk[2 * t + 1])};
         const size_t n_chunks = (r1 - r0 + chunk_rows - 1) / chunk_rows;
         auto issue = [&](size_t c) {
             const size_t a = r0 + c * chunk_rows, b = std::min(r1, a + chunk_rows);

@@ -497,9 +497,9 @@ static int panel_upload_impl(genphi_panel *p, int device)
     for (int c = 0; c < L; ++c)
         PN_TRY(up(p->member[c].data(), p->member[c].size() * sizeof(int), reinterpret_cast<void **>(&p->d_member[c])));
     {
-        hipDeviceProp_t prop;
-        PN_TRY(hipGetDeviceProperties(&prop, device));
-        p->n_cus = std::max(8, prop.multiProcessorCount / 8 * 8);
+        int cus = 0;
+        PN_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        p->n_cus = std::max(8, cus / 8 * 8);
     }
     p->glist_cap = static_cast<int>((pl.max_cut + 64) / 64 * 64);
     p->ev.assign(2 * S, nullptr);

@@ -20,7 +20,6 @@
 #include <cstring>
 #include <numeric>
 #include <thread>
-#include <unordered_map>
 
 #include "../../include/genphi.h"
 
@@ -40,18 +39,25 @@ void counting_sort(const std::vector<int32_t> &in, std::vector<int32_t> &out, co
 }
 
 // ID -> rank index.  Pedigree IDs are usually small dense integers: a direct table then; anything
-// else (sparse, huge or negative labels -- IDs are Julia Int) goes through a hash map.
+// else (sparse, huge or negative labels -- IDs are Julia Int) goes through an open-addressing hash table
+// (genea140: 41,523 IDs up to 900,506 -- a direct table of 3.6 MB costs its page faults on every plan, std::unordered_map
+// a node allocation per individual: 0.9 of the 3.7 ms of that plan).
 class IdMap {
 public:
     void init(int64_t n, const int64_t *ind)
     {
         int64_t lo = INT64_MAX, hi = INT64_MIN;
         for (int64_t i = 0; i < n; ++i) { lo = std::min(lo, ind[i]); hi = std::max(hi, ind[i]); }
-        if (n > 0 && lo >= 0 && hi < 8 * n + 1024) {
+        if (n > 0 && lo >= 0 && hi < 3 * n + 1024) {
             table_.assign(static_cast<size_t>(hi) + 1, -1);
             direct_ = true;
         } else {
-            map_.reserve(static_cast<size_t>(n) * 2);
+            int bits = 4;
+            while ((int64_t(1) << bits) < 2 * n + 2) ++bits;
+            shift_ = 64 - bits;
+            keys_.assign(size_t(1) << bits, 0);
+            vals_.assign(size_t(1) << bits, -1);
+            mask_ = (size_t(1) << bits) - 1;
         }
     }
     // false when the ID is already present
@@ -62,18 +68,32 @@ public:
             table_[id] = rank;
             return true;
         }
-        return map_.emplace(id, rank).second;
+        size_t h = slot(id);
+        while (vals_[h] >= 0) {
+            if (keys_[h] == id) return false;
+            h = (h + 1) & mask_;
+        }
+        keys_[h] = id; vals_[h] = rank;
+        return true;
     }
     int32_t find(int64_t id) const      // -1 when absent
     {
         if (direct_) return (id < 0 || id >= static_cast<int64_t>(table_.size())) ? -1 : table_[id];
-        auto it = map_.find(id);
-        return it == map_.end() ? -1 : it->second;
+        size_t h = slot(id);
+        while (vals_[h] >= 0) {
+            if (keys_[h] == id) return vals_[h];
+            h = (h + 1) & mask_;
+        }
+        return -1;
     }
 private:
+    size_t slot(int64_t id) const { return static_cast<size_t>((static_cast<uint64_t>(id) * 0x9E3779B97F4A7C15ull) >> shift_); }
     bool direct_ = false;
     std::vector<int32_t> table_;
-    std::unordered_map<int64_t, int32_t> map_;
+    std::vector<int64_t> keys_;
+    std::vector<int32_t> vals_;
+    size_t mask_ = 0;
+    int shift_ = 0;
 };
 
 int mode_for(int64_t n_prev, const PlanOptions &opt)
@@ -298,6 +318,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     }
     if (n_ind >= (int64_t(1) << 31) - 1) { err = "pedigree too large (>= 2^31 individuals)"; return GENPHI_ERR_ARG; }
 
+    PhaseTrace trace;
     // ---- id -> rank index; parents must precede children (src/create.jl:234-254) ----------
     IdMap rank_of;
     rank_of.init(n_ind, ind);
@@ -327,6 +348,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         fa[i] = f; mo[i] = m;
     }
 
+    trace.mark("  plan: ids, parents");
     // ---- probands: first occurrences, in the caller's order (`∩` at src/compute.jl:251) ----
     std::vector<int32_t> tfirst(n_ind, -1), tlast(n_ind, -1), stamp(n_ind, -1);
     std::vector<int32_t> cur;
@@ -359,6 +381,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         cur.swap(nxt);
         ++t;
     }
+    trace.mark("  plan: generations");
     const int32_t L = t;                     // number of cuts (0 when there are no probands)
     plan.n_levels = L;
     if (L == 0) return GENPHI_OK;
@@ -382,6 +405,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         int64_t run = 0;
         for (int32_t c = 0; c < L; ++c) { run += diff[c]; size_of[c] = run; }
     }
+    trace.mark("  plan: buckets, cut sizes");
     // Block assembly (kModeWide) per cut: blk[c] = the step that produces cut c assembles its level block by block.  Always so when a
     // source row does not fit in LDS; beyond that, steps of narrower cuts are switched to it when a run of them can be kept IN PLACE
     // (LevelStep::stay) and the bytes saved -- the dragged x dragged block is most of a level of overlapping generations, real
@@ -501,6 +525,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         }
     }
 
+    trace.mark("  plan: cost model, orders");
     // ---- storage order of every cut: [dragged by previous position..., new by rank...];
     //      the last cut keeps the proband order (contractual) unless its step is WIDE ----------
     std::vector<std::vector<int32_t>> cut(L);
@@ -519,6 +544,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         plan.ld[c] = pitch_for(plan.cut_sizes[c]);
         plan.max_cut = std::max(plan.max_cut, plan.cut_sizes[c]);
     }
+    trace.mark("  plan: cuts");
     // ---- runs of WIDE steps whose members stay in place (see LevelStep::stay) ---------------------------------
     // stay_c[c]: the step producing cut c writes in place; slotP[c] > 0: cut c is stored by slot, capacity slotP[c];
     // slots_c[c][k]: slot of member k of cut c; abs?_c[c][k]: slots of the sources (in cut c - 1) of member k of cut c
@@ -658,6 +684,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     plan.both_counts.assign(L - 1, 0);
     plan.steps.resize(L - 1);
 
+    trace.mark("  plan: slots");
     // ---- positions chain through the cuts: one serial, linear pass snapshots, for every member
     //      of cut c, the positions of its sources in cut c-1 (-1 = none) ----------------------------
     std::vector<std::vector<int32_t>> posA(L), posB(L);
@@ -680,6 +707,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         }
     }
 
+    trace.mark("  plan: positions");
     // ---- the flat index arrays of every step: independent of each other, built by a few threads ----
     auto build_step = [&](int32_t c, ReuseScratch &w) {
         LevelStep &st = plan.steps[c - 1];
@@ -804,6 +832,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
         for (char e : oom) if (e) throw std::bad_alloc();
     }
 
+    trace.mark("  plan: step arrays");
     double bytes = 0.0;
     for (int32_t c = 0; c + 1 < L; ++c) {
         const double a = static_cast<double>(plan.cut_sizes[c]), b = static_cast<double>(plan.cut_sizes[c + 1]);

@@ -23,7 +23,10 @@
 // sources of the dragged columns increase monotonically (a level's dragged x dragged block is a
 // stream compaction of the previous matrix), (iii) the new x new block is contiguous.
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -162,5 +165,20 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
                     const int *out_rows, int n_rows, int seg_cap, int max_run, WalkLists &out);
 
 inline int64_t pitch_for(int64_t n) { return ((n + 1) + 63) / 64 * 64; }
+
+// GENPHI_TRACE=1: wall-clock marks of the phases of a call on stderr (planner, upload, sweep): where does the host side of a call go?
+struct PhaseTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    PhaseTrace() : on(std::getenv("GENPHI_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), last(t0) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[genphi trace] %-28s +%8.3f ms  (at %8.3f ms)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+                     std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 }  // namespace genphi

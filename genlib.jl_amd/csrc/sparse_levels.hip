@@ -27,6 +27,8 @@
 // rank words are needed: every grouping of the reference's sum is exact.
 #include "sparse_levels.h"
 
+#include "devcache.h"
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -65,8 +67,8 @@ struct SpArgs {
     unsigned *rnz_out;            // (calibration run) non-zero entries of every row of Psi_{s+1}
     int wp;                       // bitmap words in LDS: workgroup size x an odd number
     int cap;                      // entries of one row of Psi_{s+1} the LDS holds
-    unsigned *stat;               // [0] entries of Y written so far, [1] longest row of Psi, [2] 1 = a row or the arena overflowed, 2 = a row's
-                                  // length differs from the plan's, [3] non-zero entries of Psi (calibration run)
+    unsigned *stat;               // [0] entries of Y written so far (calibration run), [2] 1 = a row or the arena overflowed, 2 = a row's length
+                                  // differs from the plan's
     // sparse -> dense step
     float *out;
     long long ld;
@@ -288,11 +290,9 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
             if (tid == 0) { atomicOr(&a.stat[2], 1u); a.rowd_out[i] = make_uint2(0u, 0u); a.rnz_out[i] = 0u; }
             return;
         }
-        if (tid == 0) {
+        if (tid == 0) {                                    // (the host takes the longest row and the number of non-zero entries from rnz)
             a.rowd_out[i] = make_uint2(off, ltot);
             a.rnz_out[i] = static_cast<unsigned>(total);
-            atomicMax(&a.stat[1], static_cast<unsigned>(total));
-            atomicAdd(&a.stat[3], static_cast<unsigned>(total));
         }
     }
     const unsigned run = expand(true, off, a.fixed ? place.y : 0xffffffffu);
@@ -414,6 +414,7 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
                                    hipStream_t stream, std::string &err)
 {
     if (S < 2 || static_cast<int>(dev.size()) < S) { err = "sparse_levels_create: nothing eligible"; return nullptr; }
+    PhaseTrace trace;
     SparseLevels *sl = new (std::nothrow) SparseLevels();
     if (!sl) { err = "out of memory"; return nullptr; }
     sl->S = S; sl->tun = tun; sl->dev.assign(dev.begin(), dev.begin() + S);
@@ -455,8 +456,9 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
         total += al256(off.size() * sizeof(int)) + al256(ch.size() * sizeof(unsigned)) + al256(moff.size() * sizeof(int)) + al256(mt.size() * sizeof(uint2));
     }
     sl->n_ent[0] = sl->n_ch[0];
+    trace.mark("  sparse: children, mates (host)");
     auto fail = [&](const std::string &m) { err = m; sparse_levels_destroy(sl); return static_cast<SparseLevels *>(nullptr); };
-    if (hipMalloc(reinterpret_cast<void **>(&sl->blob), total) != hipSuccess) return fail("hipMalloc (children lists) failed");
+    if (cached_malloc(reinterpret_cast<void **>(&sl->blob), total) != hipSuccess) return fail("hipMalloc (children lists) failed");
     std::vector<char> host(total, 0);
     size_t o = 0;
     sl->ch_off.resize(S); sl->ch.resize(S); sl->mt_off.resize(S); sl->mt.resize(S);
@@ -474,6 +476,7 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     }
     if (hipMemcpyAsync(sl->blob, host.data(), total, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return fail("upload of the children lists failed");
+    trace.mark("  sparse: lists to device");
     // arenas: the rows of Y of cuts 0..S-1 (a non-zero entry of Psi has about two children; the calibration also writes the cut
     // that turns out too dense, until the arena is full)
     int n_max = 0;
@@ -483,25 +486,26 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     want = std::min(want, 4.0e9);                      // (32-bit cursor)
     sl->ent_cap = static_cast<size_t>(want);
     for (int b = 0; b < 2; ++b)
-        if (hipMalloc(reinterpret_cast<void **>(&sl->ent[b]), sl->ent_cap * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row-list arena) failed");
+        if (cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), sl->ent_cap * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row-list arena) failed");
     size_t rowd_total = 0, fm_total = 0;
     auto pad32 = [](int n) { return (static_cast<size_t>(n) + 32) / 32 * 32; };
     for (int c = 0; c < S; ++c) { rowd_total += pad32(sl->n_of[c]); fm_total += pad32(sl->n_of[c + 1]); }
-    if (hipMalloc(reinterpret_cast<void **>(&sl->rowd_blob), rowd_total * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row descriptors) failed");
-    if (hipMalloc(reinterpret_cast<void **>(&sl->fm_blob), fm_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (parents' kinships) failed");
-    if (hipMalloc(reinterpret_cast<void **>(&sl->rnz_blob), rowd_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (row lengths) failed");
-    if (hipMalloc(reinterpret_cast<void **>(&sl->order_blob), rowd_total * sizeof(int)) != hipSuccess) return fail("hipMalloc (row order) failed");
+    if (cached_malloc(reinterpret_cast<void **>(&sl->rowd_blob), rowd_total * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row descriptors) failed");
+    if (cached_malloc(reinterpret_cast<void **>(&sl->fm_blob), fm_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (parents' kinships) failed");
+    if (cached_malloc(reinterpret_cast<void **>(&sl->rnz_blob), rowd_total * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (row lengths) failed");
+    if (cached_malloc(reinterpret_cast<void **>(&sl->order_blob), rowd_total * sizeof(int)) != hipSuccess) return fail("hipMalloc (row order) failed");
     sl->rowd.resize(S); sl->fm.resize(S); sl->rnz.resize(S); sl->order.resize(S); sl->cls.assign(S, std::array<int, 4>{0, 0, 0, 0});
     for (size_t c = 0, at = 0, fat = 0; c < static_cast<size_t>(S); ++c) {
         sl->rowd[c] = sl->rowd_blob + at; sl->rnz[c] = sl->rnz_blob + at; sl->order[c] = sl->order_blob + at; at += pad32(sl->n_of[c]);
         sl->fm[c] = sl->fm_blob + fat; fat += pad32(sl->n_of[c + 1]);
     }
-    if (hipMalloc(reinterpret_cast<void **>(&sl->stat), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (counters) failed");
-    if (hipHostMalloc(reinterpret_cast<void **>(&sl->stat_host), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+    if (cached_malloc(reinterpret_cast<void **>(&sl->stat), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess) return fail("hipMalloc (counters) failed");
+    if (cached_pinned(reinterpret_cast<void **>(&sl->stat_host), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess)
         return fail("hipHostMalloc (counters) failed");
     std::memset(sl->stat_host, 0, 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned));
     sl->bytes = static_cast<double>(total) + 2.0 * sl->ent_cap * sizeof(uint2) + static_cast<double>(rowd_total * sizeof(uint2) + fm_total * sizeof(unsigned));
     sl->cap_cal = std::min(8192, (n_max + 63) / 64 * 64);
+    trace.mark("  sparse: arenas");
     if (static_cast<size_t>(sl->n_ch[0]) > sl->ent_cap) return fail("sparse levels: arena smaller than the first cut");
     return sl;
 }
@@ -509,14 +513,14 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
 void sparse_levels_destroy(SparseLevels *sl)
 {
     if (!sl) return;
-    if (sl->blob) (void)hipFree(sl->blob);
-    for (int b = 0; b < 2; ++b) if (sl->ent[b]) (void)hipFree(sl->ent[b]);
-    if (sl->rowd_blob) (void)hipFree(sl->rowd_blob);
-    if (sl->fm_blob) (void)hipFree(sl->fm_blob);
-    if (sl->rnz_blob) (void)hipFree(sl->rnz_blob);
-    if (sl->order_blob) (void)hipFree(sl->order_blob);
-    if (sl->stat) (void)hipFree(sl->stat);
-    if (sl->stat_host) (void)hipHostFree(sl->stat_host);
+    if (sl->blob) (void)cached_free(sl->blob);
+    for (int b = 0; b < 2; ++b) if (sl->ent[b]) (void)cached_free(sl->ent[b]);
+    if (sl->rowd_blob) (void)cached_free(sl->rowd_blob);
+    if (sl->fm_blob) (void)cached_free(sl->fm_blob);
+    if (sl->rnz_blob) (void)cached_free(sl->rnz_blob);
+    if (sl->order_blob) (void)cached_free(sl->order_blob);
+    if (sl->stat) (void)cached_free(sl->stat);
+    cached_pinned_release(sl->stat_host);
     delete sl;
 }
 
@@ -595,8 +599,9 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     if (sl->tun.force_k == -1) { sl->calibrated = true; return GENPHI_OK; }
     int last = 0;                                          // last cut whose lists exist
     const bool trace = std::getenv("GENPHI_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
     std::vector<unsigned> rnz;
-    std::vector<int> order;
+    std::vector<int> order, cnt;
     int rc = launch_identity(sl, stream, err);
     if (rc) return rc;
     for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be kept as lists only when step s+1 is eligible too
@@ -610,26 +615,36 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         SP_TRY(hipMemcpyAsync(rnz.data(), sl->rnz[s + 1], static_cast<size_t>(n) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         SP_TRY(hipStreamSynchronize(stream));
         if (st[2] != 0) break;                             // a row or the arena overflowed: too dense for lists
-        sl->nnz[s + 1] = static_cast<long long>(st[3]);
+        long long nnz = 0;
+        unsigned longest = 0;
+        for (int q = 0; q < n; ++q) { nnz += rnz[q]; longest = std::max(longest, rnz[q]); }
+        sl->nnz[s + 1] = nnz;
         sl->n_ent[s + 1] = static_cast<long long>(st[0]);
-        sl->max_row[s + 1] = static_cast<int>(st[1]);
-        // the rows of cut s+1 by length, longest first: a launch per class of lengths, each with the LDS its rows need
+        sl->max_row[s + 1] = static_cast<int>(longest);
+        // the rows of cut s+1 by length, longest first (a counting sort; lengths are <= cap_cal): a launch per class of lengths, each
+        // with the LDS its rows need
         order.resize(n);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return rnz[x] > rnz[y]; });
+        cnt.assign(static_cast<size_t>(longest) + 2, 0);
+        for (int q = 0; q < n; ++q) cnt[longest - rnz[q] + 1]++;
+        for (unsigned v = 0; v <= longest; ++v) cnt[v + 1] += cnt[v];
+        for (int q = 0; q < n; ++q) order[cnt[longest - rnz[q]]++] = q;
         std::array<int, 4> &cl = sl->cls[s + 1];
         cl = {0, 0, 0, n};
-        for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; if (rnz[order[q]] > 256u) cl[2] = q + 1; }
+        for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; else if (rnz[order[q]] > 256u) cl[2] = q + 1; else break; }
+        cl[2] = std::max(cl[2], cl[1]);
         SP_TRY(hipMemcpyAsync(sl->order[s + 1], order.data(), static_cast<size_t>(n) * sizeof(int), hipMemcpyHostToDevice, stream));
         SP_TRY(hipStreamSynchronize(stream));
         last = s + 1;
         const double dn = static_cast<double>(n);
-        if (trace)
+        if (trace) {
+            const auto t_now = std::chrono::steady_clock::now();
             std::fprintf(stderr, "[genphi trace]   sparse cut %2d: %6d members, %10lld non-zero (%.4f), %10lld list entries, longest row %5d, rows > 1024 / > 256: %d / %d; "
-                         "est. list step %.3f ms, dense step %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
-                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s));
+                         "est. list step %.3f ms, dense step %.3f ms; calibrated in %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
+                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s), std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+            t_prev = t_now;
+        }
         if (sl->tun.force_k < 0) {
-            if (static_cast<double>(st[3]) > sl->tun.max_permille / 1000.0 * dn * dn) break;
+            if (static_cast<double>(nnz) > sl->tun.max_permille / 1000.0 * dn * dn) break;
             if (t_list_step(sl, s) > 2.0 * t_dense_step(sl, s) + 0.02) break;     // (it only gets denser)
         }
     }
@@ -654,6 +669,20 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         if (widest < sl->tun.min_cut) return GENPHI_OK;
     }
     sl->k = k;
+    {   // the arenas of the calibration run were sized for cuts of unknown density: now each holds exactly the largest cut it is used for
+        size_t need[2] = {1024, 1024};
+        for (int c = 0; c <= k; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>(sl->n_ent[c]) + 64);
+        SP_TRY(hipStreamSynchronize(stream));
+        for (int b = 0; b < 2; ++b) {
+            if (need[b] * 2 > sl->ent_cap) { need[b] = sl->ent_cap; continue; }      // (not worth a reallocation)
+            (void)cached_free(sl->ent[b]);
+            sl->ent[b] = nullptr;
+            SP_TRY(cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), need[b] * sizeof(uint2)));
+        }
+        sl->bytes -= 2.0 * sl->ent_cap * sizeof(uint2);
+        sl->bytes += static_cast<double>((need[0] + need[1]) * sizeof(uint2));
+        sl->ent_cap = std::min(need[0], need[1]);          // (what the kernels check writes against)
+    }
     if (trace) std::fprintf(stderr, "[genphi trace]   sparse cuts 0..%d\n", k);
     return GENPHI_OK;
 }

@@ -56,6 +56,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "devcache.h"
 #include "../../include/genphi.h"
 
 int genphi_set_error(int code, const std::string &msg);      // genphi_hip.hip
@@ -426,8 +427,33 @@ struct DeviceSide {
 };
 std::mutex g_side_mu;
 DeviceSide g_side_kept;
+// pinned staging buffer of the proband block, kept between calls; capped (kPinCap): larger blocks take the plain 2D copy
+std::mutex g_pin_mu;
+void *g_pin = nullptr;
+size_t g_pin_bytes = 0;
+constexpr size_t kPinCap = size_t(256) << 20;
 
 }  // namespace
+
+// what gen.sparse_phi keeps between calls (the device side of the last call, the pinned staging buffer) goes back to the
+// driver: part of genphi_release_cached
+void genphi::sparse_phi_release_kept()
+{
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        if (g_side_kept.st || g_side_kept.pool) {
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (g_side_kept.device >= 0) (void)hipSetDevice(g_side_kept.device);
+            g_side_kept.destroy();
+            g_side_kept = DeviceSide();
+            if (cur >= 0) (void)hipSetDevice(cur);
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    if (g_pin) (void)hipHostFree(g_pin);
+    g_pin = nullptr; g_pin_bytes = 0;
+}
 
 struct genphi_sparse {
     int64_t n_pro = 0;                        // distinct probands
@@ -778,16 +804,15 @@ static int sparse_impl(int64_t n_ind, const int64_t *ind, const int64_t *father,
         if (N > 0) {
             // through a pinned staging buffer kept for the life of the process (a 2D copy into pageable memory runs at ~6 GB/s:
             // 2.7 of the 12 ms of a call at 2,000 probands), in four row bands so that the host copy of a band runs under the next one's transfer
-            static std::mutex pin_mu;
-            static void *pin = nullptr;
-            static size_t pin_bytes = 0;
-            std::lock_guard<std::mutex> lock(pin_mu);
+            // (capped at 256 MB -- 8,192 probands --: beyond, the plain 2D copy; released by genphi_release_cached)
+            std::lock_guard<std::mutex> lock(g_pin_mu);
             const size_t need = static_cast<size_t>(N * N) * sizeof(float);
-            if (pin_bytes < need) {
-                if (pin) (void)hipHostFree(pin);
-                pin = nullptr; pin_bytes = 0;
-                if (hipHostMalloc(&pin, need, hipHostMallocDefault) == hipSuccess) pin_bytes = need; else { (void)hipGetLastError(); pin = nullptr; }
+            if (g_pin_bytes < need && need <= kPinCap) {
+                if (g_pin) (void)hipHostFree(g_pin);
+                g_pin = nullptr; g_pin_bytes = 0;
+                if (hipHostMalloc(&g_pin, need, hipHostMallocDefault) == hipSuccess) g_pin_bytes = need; else { (void)hipGetLastError(); g_pin = nullptr; }
             }
+            void *pin = g_pin_bytes >= need ? g_pin : nullptr;
             if (pin) {
                 constexpr int kBands = 4;
                 const size_t ev0 = timed ? waves.size() + 1 : 0;             // (after the waves' timing events)

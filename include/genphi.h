@@ -137,6 +137,10 @@ int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user);
  * entries of cut c for the cuts that were counted (-1 = not counted), at most `cap` entries; returns how many were filled.          */
 int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap);
 
+/* Device memory the plan holds right now, in bytes (level matrices, row lists of the sparse cuts, the resident result, the index
+ * arrays): 0 before the first compute and after genphi_plan_release_device.  What a cache of plans budgets with.             */
+int64_t genphi_plan_device_bytes(const genphi_plan *plan);
+
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);
 
@@ -223,6 +227,15 @@ int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, c
                      const int64_t *sex, int64_t n_pro, const int64_t *pro, int64_t n_anc,
                      const int64_t *ancestors, int64_t *n_out, int64_t **ind_out, int64_t **father_out,
                      int64_t **mother_out, int64_t **sex_out);
+
+/* What the library keeps between calls, per process: device blocks of released plans (up to GENPHI_KEEP_MB, default 1024 MiB per
+ * device, handed to the next plan instead of hipMalloc / hipFree), idle streams, the pinned staging ring of genphi_result_to_host,
+ * and the device side + pinned buffer of the last genphi_sparse_phi call (up to GENPHI_SPARSE_KEEP_MB, default 1024).  A one-shot
+ * gen.phi call on a mid-size pedigree otherwise spends most of its time in the allocator.  genphi_release_cached gives all of it
+ * back to the driver (plans in use are not touched); genphi_cached_bytes = device bytes kept right now.  The reference has no
+ * counterpart: its matrices are garbage-collected Julia arrays (src/compute.jl:291,301).                                      */
+void genphi_release_cached(void);
+int64_t genphi_cached_bytes(void);
 
 /* Releases everything the plan holds on its GPU (index arrays, level matrices, the resident
  * result, streams, captured graphs) and keeps the host-side plan: the next genphi_compute_device
