@@ -100,7 +100,7 @@ def lib():
         L.genphi_release_cached.restype = None
         L.genphi_cached_bytes.argtypes = []
         L.genphi_cached_bytes.restype = C.c_int64
-        L.genphi_plan_sparse_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _I64P, C.c_int32]
+        L.genphi_plan_sparse_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _I64P, _I64P, C.c_int32]
         L.genphi_plan_sparse_levels.restype = C.c_int
         L.genphi_plan_algorithmic_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_algorithmic_bytes.restype = C.c_double
@@ -383,8 +383,14 @@ class PhiPlan:
         sweep has run yet) and the non-zero entries counted per cut (-1 = not counted), genphi_plan_sparse_levels."""
         k = C.c_int32(-1)
         buf = (C.c_int64 * 16)()
-        m = lib().genphi_plan_sparse_levels(self._h, C.byref(k), buf, 16)
+        m = lib().genphi_plan_sparse_levels(self._h, C.byref(k), buf, None, 16)
         return int(k.value), [int(buf[c]) for c in range(m)]
+
+    def sparse_entries(self):
+        """List entries ((column, value) pairs, 8 bytes each) every counted cut is stored as; -1 = not counted."""
+        buf = (C.c_int64 * 16)()
+        m = lib().genphi_plan_sparse_levels(self._h, None, None, buf, 16)
+        return [int(buf[c]) for c in range(m)]
 
     def _opts(self, device, kernel, rows, timing, storage64=False, no_graph=False, no_sparse=False):
         o = GenphiOpts()

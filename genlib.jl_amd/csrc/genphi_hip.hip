@@ -1959,6 +1959,9 @@ int genphi_set_error(int code, const std::string &msg) { return fail(code, msg);
 constexpr size_t kTailPadFloats = 64 * 1024;
 // pk / ord are padded so that the unrolled per-thread column loops need no clamp
 constexpr size_t kIdxPad = 32 * 1024;
+// ... which only the SPLIT kernels do (a chunk of up to 24 x 1024 columns whatever the cut's width); the FULL kernel reads whole quads
+// (a deep pedigree of 200 tiny levels carried 52 MB of padding: 11 of the 14 ms of its first call)
+static size_t idx_pad(const LevelStep &s) { return s.mode == genphi::kModeSplit ? kIdxPad : 1024; }
 
 // Tuning, A/B and test hooks.  Every one is an environment variable that is read ONCE, when the plan is
 // created (genphi_plan_create), and kept in the plan: a plan never changes behaviour under the caller's
@@ -2357,14 +2360,14 @@ int64_t genphi_plan_device_bytes(const genphi_plan *p)
                      genphi::sparse_levels_device_bytes(p->sparse);
     return static_cast<int64_t>(b);
 }
-int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap)
+int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int64_t *entries, int32_t cap)
 {
     if (k_out) *k_out = -1;
     if (!plan || !plan->sparse) return 0;
     if (k_out) *k_out = genphi::sparse_levels_k(plan->sparse);
-    std::vector<long long> v(std::max(cap, 0), -1);
-    const int m = genphi::sparse_levels_counts(plan->sparse, cap, v.data(), nullptr);
-    for (int c = 0; c < m && nnz; ++c) nnz[c] = v[c];
+    std::vector<long long> v(std::max(cap, 0), -1), e(std::max(cap, 0), -1);
+    const int m = genphi::sparse_levels_counts(plan->sparse, cap, v.data(), e.data(), nullptr);
+    for (int c = 0; c < m; ++c) { if (nnz) nnz[c] = v[c]; if (entries) entries[c] = e[c]; }
     return m;
 }
 int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user)
@@ -2484,7 +2487,7 @@ static int upload_plan_impl(genphi_plan *p, int device)
     }
     for (size_t k = 0; k < n_all; ++k) {
         const LevelStep &s = step_at(k);
-        total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + kIdxPad) * sizeof(int));
+        total += 3 * al(s.n * sizeof(int)) + 2 * al((s.n + idx_pad(s)) * sizeof(int));
         if (s.mode == genphi::kModeSplit && !step_groups[k].w.run.empty()) total += groups_bytes(step_groups[k]);
         if (s.mode == genphi::kModeWide)
             total += al(s.n * sizeof(int4)) + al(s.parents.size() * sizeof(int4)) + al(s.parents.size() * sizeof(int)) +
@@ -2512,13 +2515,13 @@ static int upload_plan_impl(genphi_plan *p, int device)
         DeviceStep &d = k < n_main ? p->dsteps[k] : p->nn_dsteps[k - n_main];
         d.srcA = reinterpret_cast<int *>(put(s.srcA.data(), s.n * sizeof(int)));
         d.srcB = reinterpret_cast<int *>(put(s.srcB.data(), s.n * sizeof(int)));
-        d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int), kIdxPad * sizeof(int)));
+        d.ord = reinterpret_cast<int *>(put(s.ord.data(), s.n * sizeof(int), idx_pad(s) * sizeof(int)));
         d.work = reinterpret_cast<int *>(put(s.work.data(), s.work.size() * sizeof(int)));
-        d.pk = reinterpret_cast<unsigned *>(put(s.pk.data(), s.pk.size() * sizeof(unsigned), kIdxPad * sizeof(unsigned)));
+        d.pk = reinterpret_cast<unsigned *>(put(s.pk.data(), s.pk.size() * sizeof(unsigned), idx_pad(s) * sizeof(unsigned)));
         if (!s.pk.empty()) {      // padding entries point both sources at the zero column
             unsigned *hp = reinterpret_cast<unsigned *>(host.data() + (reinterpret_cast<char *>(d.pk) - p->idx_blob));
             const unsigned zero_pk = static_cast<unsigned>(s.n_prev) | (static_cast<unsigned>(s.n_prev) << 16);
-            for (size_t k2 = s.pk.size(); k2 < s.pk.size() + kIdxPad; ++k2) hp[k2] = zero_pk;
+            for (size_t k2 = s.pk.size(); k2 < s.pk.size() + idx_pad(s); ++k2) hp[k2] = zero_pk;
         }
         if (s.mode == genphi::kModeSplit && !step_groups[k].w.run.empty()) put_groups(step_groups[k], d.groups, put);
         if (s.mode == genphi::kModeWide) {

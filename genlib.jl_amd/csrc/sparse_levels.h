@@ -72,7 +72,7 @@ int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long
 int sparse_levels_enqueue_flags(SparseLevels *sl, hipStream_t stream, std::string &err);
 bool sparse_levels_flags_ok(const SparseLevels *sl);
 // diagnostics: per cut c <= k (+1 from the calibration run) the number of non-zero entries (-1 unknown) and the longest row
-int sparse_levels_counts(const SparseLevels *sl, int cap, long long *nnz, int *max_row);
+int sparse_levels_counts(const SparseLevels *sl, int cap, long long *nnz, long long *entries, int *max_row);
 double sparse_levels_device_bytes(const SparseLevels *sl);
 
 }  // namespace genphi

@@ -741,12 +741,13 @@ bool sparse_levels_flags_ok(const SparseLevels *sl)
     return true;
 }
 
-int sparse_levels_counts(const SparseLevels *sl, int cap, long long *nnz, int *max_row)
+int sparse_levels_counts(const SparseLevels *sl, int cap, long long *nnz, long long *entries, int *max_row)
 {
     if (!sl) return 0;
     const int m = std::min(cap, sl->S + 1);
     for (int c = 0; c < m; ++c) {
         if (nnz) nnz[c] = sl->nnz[c];
+        if (entries) entries[c] = sl->n_ent[c];
         if (max_row) max_row[c] = sl->max_row[c];
     }
     return m;

@@ -134,8 +134,10 @@ int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user);
  * the sweep keeps cuts 0..k as lists of their non-zero entries -- what the reference's sparse_phi stores, src/compute.jl:391-394 --
  * and step k writes cut k+1 as the first dense matrix.  k is fixed by the first genphi_compute_device of the plan, which counts the
  * non-zero entries of the leading cuts on the GPU.  *k_out = k (-1: every level is dense, or no sweep has run yet); nnz[c] = non-zero
- * entries of cut c for the cuts that were counted (-1 = not counted), at most `cap` entries; returns how many were filled.          */
-int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int32_t cap);
+ * entries of cut c for the cuts that were counted (-1 = not counted), entries[c] = the (column, value) pairs cut c is stored as (each
+ * non-zero entry once per child of its column: 8 bytes each; what a sparse step reads and writes), at most `cap` of each (either
+ * may be NULL); returns how many were filled.                                                                                   */
+int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int64_t *entries, int32_t cap);
 
 /* Device memory the plan holds right now, in bytes (level matrices, row lists of the sparse cuts, the resident result, the index
  * arrays): 0 before the first compute and after genphi_plan_release_device.  What a cache of plans budgets with.             */
