@@ -26,6 +26,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A/B runs of this script steer the library through GENPHI_* environment hooks, which it reads only under GENPHI_ENV_HOOKS=1
+_NOT_AB = ("GENPHI_TRACE", "GENPHI_D2H_THREADS", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE", "GENPHI_ENV_HOOKS", "GENPHI_PLAN_CACHE", "GENPHI_KEEP_MB")
+if any(k.startswith("GENPHI_") and k not in _NOT_AB for k in os.environ):
+    os.environ.setdefault("GENPHI_ENV_HOOKS", "1")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -356,6 +360,8 @@ def run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes,
                                       + (" (all ranks share one GPU: rehearsal)" if args.single_device and world > 1 else ""),
                        "why_exchange": "forced" if fits else "two level matrices do not fit one GPU",
                        "exchange_bytes_sent_per_rank_max": sent_max, "comm_selftest": selftest,
+                       # what the all-to-alls of a sweep would take at the xGMI peer bandwidth (7 links x ~153 GB/s per GPU, all used at once)
+                       "exchange_ms_predicted_xgmi": sent_max / (7 * 153e9) * 1e3 if world > 1 else 0.0,
                        "panel_device_bytes": pl.device_bytes, "max_cut": max(cut_sizes),
                        "panel_step_modes": pl.step_modes() if hasattr(pl, "step_modes") else None,
                        "ordering": "host synchronisation per step" if args.panel_host_sync else "stream events (no host synchronisation inside a sweep)",
@@ -460,6 +466,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world > 1:
+        # row shards: a proband cut that stayed in place would make every rank compute the whole last level before delivering its
+        # rows; the proband step keeps its row kernel and its shards instead (the planner's cost model knows nothing about shards).
+        # (Before the library reads its hooks: the gate is read once.)
+        os.environ["GENPHI_STAY_LAST"] = "0"
+        os.environ["GENPHI_ENV_HOOKS"] = "1"
     if args.dry_run:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
@@ -487,10 +499,11 @@ def main():
         from genlib_jl_amd import distributed as gdist
         probe = gen.plan(ped, pro)
         cut_sizes, both_counts = probe.levels()
+        plan_bytes = probe.device_bytes_needed
         probe.close()
         # the decision is collective (MIN over the ranks): every rank must take the same path
         fits = gdist.replicated_levels_fit(cut_sizes, torch.cuda.mem_get_info()[0], dist=dist, device=torch.device("cuda", local_rank),
-                                           both_counts=both_counts)
+                                           both_counts=both_counts, plan_bytes=plan_bytes)
         if args.exchange or os.environ.get("GENPHI_FORCE_EXCHANGE") == "1" or not fits:
             return run_exchange(args, ped, pro, desc, dist, rank, local_rank, world, cut_sizes, fits)
     t_plan = time.perf_counter()
@@ -555,6 +568,19 @@ def main():
         torch.cuda.synchronize()
         replay_ms = (time.perf_counter() - t0r) * 1e3 / args.steps
 
+    # N > 1: every rank copies ITS row block to its host (the 40 GB copy of cfg4 split N ways: the end-to-end win of the row shards)
+    shard_d2h_ms = None
+    if world > 1 and not args.no_d2h and not f64:
+        t_own = 0.0
+        if not empty_shard:
+            barrier()
+            t0d = time.perf_counter()
+            host = pl.result_to_host()
+            t_own = (time.perf_counter() - t0d) * 1e3
+            del host
+        tt = torch.tensor([t_own], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        shard_d2h_ms = float(tt.item())
     if rank == 0:
         K = args.steps
         ms_per_step = wall * 1e3 / K
@@ -608,6 +634,11 @@ def main():
         # end to end through the C-ABI: plan (host) + first call (upload, allocation,
         # one sweep) ... + a sweep + the device-to-host copy of the N x N result.  Never `value`.
         end_to_end = {"plan_ms": plan_ms, "first_call_ms": first_call_ms, "sweep_ms": ms_per_step}
+        if shard_d2h_ms is not None:
+            end_to_end["d2h_ms"] = shard_d2h_ms
+            end_to_end["d2h_sample"] = f"every rank its own block of ~{(n + world - 1) // world} rows into a pageable host array, at the same time; MAX over the ranks"
+            end_to_end["total_ms_plan_sweep_d2h"] = plan_ms + ms_per_step + shard_d2h_ms
+            end_to_end["pairs_per_s"] = n * n / (end_to_end["total_ms_plan_sweep_d2h"] * 1e-3)
         if world == 1 and not args.no_d2h and not f64:
             import psutil
             need = n * n * 4
@@ -635,7 +666,7 @@ def main():
         traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         # (the committed traffic files were collected with the default settings: not comparable under A/B hooks that change what moves)
-        ab_hooks = [k for k in os.environ if k.startswith("GENPHI_") and k not in ("GENPHI_TRACE", "GENPHI_D2H_THREADS", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE")]
+        ab_hooks = [k for k in os.environ if k.startswith("GENPHI_") and k not in _NOT_AB]
         if os.path.exists(tpath) and not f64 and not ab_hooks:
             try:
                 tj = json.load(open(tpath))

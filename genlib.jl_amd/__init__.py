@@ -158,10 +158,10 @@ def founder(pedigree):
     return np.sort(pedigree.ind[(pedigree.father == 0) & (pedigree.mother == 0)])
 
 
-def plan(pedigree, probandIDs=None):
-    """Levelise `pedigree` for `probandIDs` (host only; no GPU needed)."""
+def plan(pedigree, probandIDs=None, tuning=None):
+    """Levelise `pedigree` for `probandIDs` (host only; no GPU needed).  tuning: a dict of settings for this plan (PhiPlan)."""
     probandIDs = pro(pedigree) if probandIDs is None else np.asarray(probandIDs, dtype=np.int64)
-    return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs)
+    return PhiPlan(pedigree.ind, pedigree.father, pedigree.mother, probandIDs, tuning=tuning)
 
 
 # gen.phi keeps the plans of its last calls per pedigree: the host prologue of the reference's phi (src/compute.jl:236-262:

@@ -44,8 +44,8 @@ class GenphiStats(C.Structure):
 
 # every symbol include/genphi.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "genphi_plan_create", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
-    "genphi_plan_algorithmic_bytes", "genphi_plan_device_bytes", "genphi_plan_sparse_levels", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
+    "genphi_plan_create", "genphi_plan_create_tuned", "genphi_tuning_create", "genphi_tuning_set", "genphi_tuning_destroy", "genphi_plan_levels", "genphi_plan_n_probands", "genphi_plan_step_mode", "genphi_plan_step_info", "genphi_plan_step_slots",
+    "genphi_plan_algorithmic_bytes", "genphi_plan_device_bytes", "genphi_plan_device_bytes_needed", "genphi_plan_sparse_levels", "genphi_plan_step_walk", "genphi_plan_set_step_hook", "genphi_compute_device", "genphi_result_device",
     "genphi_result_to_host", "genphi_result_to_host_f64", "genphi_phi_pairs", "genphi_result_sums", "genphi_result_entries",
     "genphi_compute_f32",
     "genphi_genealogy_read", "genphi_branching", "genphi_free", "genphi_release_cached", "genphi_cached_bytes", "genphi_plan_release_device", "genphi_plan_destroy",
@@ -78,6 +78,14 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.genphi_plan_create.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.POINTER(C.c_void_p)]
         L.genphi_plan_create.restype = C.c_int
+        L.genphi_plan_create_tuned.argtypes = [C.c_int64, _I64P, _I64P, _I64P, C.c_int64, _I64P, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.genphi_plan_create_tuned.restype = C.c_int
+        L.genphi_tuning_create.argtypes = []
+        L.genphi_tuning_create.restype = C.c_void_p
+        L.genphi_tuning_set.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.genphi_tuning_set.restype = C.c_int
+        L.genphi_tuning_destroy.argtypes = [C.c_void_p]
+        L.genphi_tuning_destroy.restype = None
         L.genphi_plan_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_I64P), C.POINTER(_I64P)]
         L.genphi_plan_levels.restype = C.c_int
         L.genphi_plan_n_probands.argtypes = [C.c_void_p]
@@ -94,6 +102,8 @@ def lib():
         L.genphi_plan_step_walk.restype = C.c_int
         L.genphi_plan_set_step_hook.argtypes = [C.c_void_p, STEP_FN, C.c_void_p]
         L.genphi_plan_set_step_hook.restype = C.c_int
+        L.genphi_plan_device_bytes_needed.argtypes = [C.c_void_p]
+        L.genphi_plan_device_bytes_needed.restype = C.c_int64
         L.genphi_plan_device_bytes.argtypes = [C.c_void_p]
         L.genphi_plan_device_bytes.restype = C.c_int64
         L.genphi_release_cached.argtypes = []
@@ -282,13 +292,26 @@ def branching(ind, father, mother, sex, pro=None, ancestors=None):
 class PhiPlan:
     """Owns a genphi_plan: levelisation + flat index arrays (host), level matrices (device)."""
 
-    def __init__(self, ind, father, mother, pro_ids):
+    def __init__(self, ind, father, mother, pro_ids, tuning=None):
+        """tuning: None = genphi_plan_create (the library's defaults; GENPHI_* environment hooks only under GENPHI_ENV_HOOKS=1), or a dict
+        of settings for this plan alone, e.g. {"SPARSE_K": -1} (genphi_plan_create_tuned; {} = the defaults whatever the environment says)."""
         L = lib()
         ind, father, mother, pro_ids = _i64(ind), _i64(father), _i64(mother), _i64(pro_ids)
         h = C.c_void_p()
-        rc = L.genphi_plan_create(len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P),
-                                  mother.ctypes.data_as(_I64P), len(pro_ids), pro_ids.ctypes.data_as(_I64P),
-                                  C.byref(h))
+        args = (len(ind), ind.ctypes.data_as(_I64P), father.ctypes.data_as(_I64P), mother.ctypes.data_as(_I64P), len(pro_ids),
+                pro_ids.ctypes.data_as(_I64P))
+        if tuning is None:
+            rc = L.genphi_plan_create(*args, C.byref(h))
+        else:
+            t = L.genphi_tuning_create()
+            try:
+                for k, v in tuning.items():
+                    rc = L.genphi_tuning_set(t, str(k).encode(), str(v).encode())
+                    if rc:
+                        _raise(rc)
+                rc = L.genphi_plan_create_tuned(*args, t, C.byref(h))
+            finally:
+                L.genphi_tuning_destroy(t)
         if rc:
             _raise(rc)
         self._h = h
@@ -319,6 +342,11 @@ class PhiPlan:
     def device_bytes(self):
         """Device memory the plan holds right now (index arrays, level matrices, row lists, the resident result)."""
         return int(lib().genphi_plan_device_bytes(self._h))
+
+    @property
+    def device_bytes_needed(self):
+        """Host only: device memory a full-result Float32 sweep of this plan will allocate (genphi_plan_device_bytes_needed)."""
+        return int(lib().genphi_plan_device_bytes_needed(self._h))
 
     @property
     def algorithmic_bytes(self):

@@ -45,6 +45,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -2017,14 +2018,39 @@ struct Tuning {
     int sparse_permille = -1;      // GENPHI_SPARSE_PERMILLE  tuning: a cut stays sparse while at most this share (1/1000) of its entries is non-zero
     int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
     int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
+    int d2h_chunk_mb = 0;          // GENPHI_D2H_CHUNK_MB     tuning: size of a pinned staging chunk of genphi_result_to_host (default 16, 4 for results below 2 GB)
     int sparse_classes = -1;       // GENPHI_SPARSE_CLASSES   A/B + test: 1 / 0 = a row-list step is always / never one launch per class of row lengths (default: where lengths differ much)
 };
 
-static Tuning tuning_from_env()
+// A set of "GENPHI_NAME" -> value settings handed to genphi_plan_create_tuned (include/genphi.h): the same knobs without the environment.
+struct genphi_tuning {
+    std::map<std::string, std::string> kv;
+};
+
+// every hook name a Tuning understands (genphi_tuning_set refuses anything else)
+static const char *const kTuningNames[] = {
+    "GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_NO_STAY", "GENPHI_STAY_MAX_SLOTS", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT",
+    "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS", "GENPHI_STAY_COL_FASTEST", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_TILE", "GENPHI_STAY_SLACK_PCT",
+    "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN",
+    "GENPHI_STAY_FAMILY", "GENPHI_MAX_GROUP", "GENPHI_MAX_RUN", "GENPHI_FULL_BS", "GENPHI_NO_IDENTITY", "GENPHI_CERT_MIN_EXP", "GENPHI_DBG_STEP",
+    "GENPHI_NO_FAST", "GENPHI_MAX_CPT", "GENPHI_FAST_NT", "GENPHI_WIDE_ROUTE", "GENPHI_TT_NOALIGN", "GENPHI_NO_SHARD_PRUNE", "GENPHI_SHARD_FORCE",
+    "GENPHI_SHARD_PRUNE_MIN_STEP", "GENPHI_NO_SMALL", "GENPHI_NO_GRAPH", "GENPHI_D2H_THREADS", "GENPHI_D2H_PAGEABLE", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE",
+    "GENPHI_D2H_CHUNK_MB", "GENPHI_TEST_FAIL_ALLOC", "GENPHI_SPARSE_K", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_CLASSES"};
+
+// the settings of a plan: from a genphi_tuning when one is given, else from the environment -- which the library reads only under
+// GENPHI_ENV_HOOKS=1 (planner.h: env_hook)
+static Tuning tuning_from(const genphi_tuning *tu)
 {
     Tuning t;
-    auto geti = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-    auto has = [](const char *name) { return std::getenv(name) != nullptr; };
+    auto look = [tu](const char *name) -> const char * {
+        if (tu) {
+            auto it = tu->kv.find(name);
+            return it == tu->kv.end() ? nullptr : it->second.c_str();
+        }
+        return genphi::env_hook(name);
+    };
+    auto geti = [&](const char *name, int dflt) { const char *e = look(name); return e ? std::atoi(e) : dflt; };
+    auto has = [&](const char *name) { return look(name) != nullptr; };
     t.lds_cap_floats = geti("GENPHI_LDS_CAP_FLOATS", 0);
     t.full_max_floats = geti("GENPHI_FULL_MAX_FLOATS", -1);
     t.no_stay = geti("GENPHI_NO_STAY", 0) != 0;
@@ -2053,10 +2079,10 @@ static Tuning tuning_from_env()
     t.no_fast = has("GENPHI_NO_FAST");
     t.max_cpt = geti("GENPHI_MAX_CPT", 0);
     t.fast_nt = geti("GENPHI_FAST_NT", 0);
-    if (const char *e = std::getenv("GENPHI_WIDE_ROUTE")) t.wide_route = (e[0] == 'B' || e[0] == 'b') ? 'B' : 'A';
+    if (const char *e = look("GENPHI_WIDE_ROUTE")) t.wide_route = (e[0] == 'B' || e[0] == 'b') ? 'B' : 'A';
     t.tt_noalign = has("GENPHI_TT_NOALIGN");
     t.no_shard_prune = has("GENPHI_NO_SHARD_PRUNE");
-    if (const char *e = std::getenv("GENPHI_SHARD_FORCE")) {
+    if (const char *e = look("GENPHI_SHARD_FORCE")) {
         int fs = -1, fr = -1;
         if (std::sscanf(e, "%d:%d", &fs, &fr) == 2) { t.shard_force_step = fs; t.shard_force_row = fr; }
     }
@@ -2066,7 +2092,7 @@ static Tuning tuning_from_env()
     t.d2h_threads = geti("GENPHI_D2H_THREADS", 0);
     t.d2h_pageable = has("GENPHI_D2H_PAGEABLE");
     t.d2h_sym = geti("GENPHI_D2H_SYM", -1);
-    if (const char *e = std::getenv("GENPHI_D2H_TILE")) {
+    if (const char *e = look("GENPHI_D2H_TILE")) {
         int r = 0, c = 0;
         if (std::sscanf(e, "%dx%d", &r, &c) == 2 && r >= 1 && c >= 1) { t.d2h_tile_rows = r; t.d2h_tile_cols = c; }
     }
@@ -2076,6 +2102,7 @@ static Tuning tuning_from_env()
     t.sparse_min_cut = geti("GENPHI_SPARSE_MIN_CUT", -1);
     t.sparse_chunk = geti("GENPHI_SPARSE_CHUNK", 0);
     t.sparse_classes = geti("GENPHI_SPARSE_CLASSES", -1);
+    t.d2h_chunk_mb = geti("GENPHI_D2H_CHUNK_MB", 0);
     return t;
 }
 
@@ -2272,13 +2299,13 @@ const char *genphi_version(void) { return "genphi-mi355x 0.1 (gfx950)"; }
 // indices_only: cuts and per-member sources / rank words only (no pk words, work orders or walk lists): all a
 // Float64-storage sweep needs (genphi_phi_pairs builds such a plan per call)
 static int plan_create_impl(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
-                            int64_t n_pro, const int64_t *pro_ids, bool indices_only, genphi_plan **out)
+                            int64_t n_pro, const int64_t *pro_ids, bool indices_only, genphi_plan **out, const genphi_tuning *tuning = nullptr)
 {
     if (!out) return fail(GENPHI_ERR_ARG, "genphi_plan_create: out is NULL");
     *out = nullptr;
     genphi_plan *p = new (std::nothrow) genphi_plan();
     if (!p) return fail(GENPHI_ERR_ALLOC, "out of memory");
-    p->tun = tuning_from_env();
+    p->tun = tuning_from(tuning);
     p->popt.indices_only = indices_only;
     if (p->tun.lds_cap_floats >= 16) p->popt.lds_cap_floats = p->tun.lds_cap_floats;
     if (p->tun.full_max_floats >= 0) p->popt.full_max_floats = p->tun.full_max_floats;
@@ -2311,6 +2338,23 @@ int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
                        int64_t n_pro, const int64_t *pro_ids, genphi_plan **out)
 {
     return plan_create_impl(n_ind, ind, father, mother, n_pro, pro_ids, false, out);
+}
+
+genphi_tuning *genphi_tuning_create(void) { return new (std::nothrow) genphi_tuning(); }
+void genphi_tuning_destroy(genphi_tuning *t) { delete t; }
+int genphi_tuning_set(genphi_tuning *t, const char *name, const char *value)
+{
+    if (!t || !name || !value) return fail(GENPHI_ERR_ARG, "genphi_tuning_set: null argument");
+    std::string key = std::strncmp(name, "GENPHI_", 7) == 0 ? name : std::string("GENPHI_") + name;
+    for (const char *k : kTuningNames)
+        if (key == k) { t->kv[key] = value; return GENPHI_OK; }
+    return fail(GENPHI_ERR_ARG, "genphi_tuning_set: unknown setting " + key);
+}
+int genphi_plan_create_tuned(int64_t n_ind, const int64_t *ind, const int64_t *father, const int64_t *mother,
+                             int64_t n_pro, const int64_t *pro_ids, const genphi_tuning *tuning, genphi_plan **out)
+{
+    static const genphi_tuning none;                       // (tuning == NULL: the defaults, whatever the environment says)
+    return plan_create_impl(n_ind, ind, father, mother, n_pro, pro_ids, false, out, tuning ? tuning : &none);
 }
 
 int genphi_plan_levels(const genphi_plan *plan, int32_t *n_levels, const int64_t **cut_sizes,
@@ -2359,6 +2403,43 @@ int64_t genphi_plan_device_bytes(const genphi_plan *p)
                      8.0 * (static_cast<double>(p->buf64_doubles[0]) + static_cast<double>(p->buf64_doubles[1]) + static_cast<double>(p->result64_doubles)) +
                      genphi::sparse_levels_device_bytes(p->sparse);
     return static_cast<int64_t>(b);
+}
+int64_t genphi_plan_device_bytes_needed(const genphi_plan *p)
+{
+    if (!p) return 0;
+    const Plan &pl = p->plan;
+    const int L = pl.n_levels;
+    if (L == 0) return 0;
+    // what upload_plan / ensure_level_buffers / genphi_compute_device allocate for a full-result Float32 sweep of this plan
+    double need[2] = {0.0, 0.0}, total = 0.0;
+    int b = 0;
+    for (int c = 0; c + 1 < L; ++c) {
+        if (c >= 1) b = pl.steps[c - 1].stay ? b : 1 - b;
+        const double rows = static_cast<double>(pl.steps[c].src_slots ? pl.steps[c].P : pl.cut_sizes[c]) + 1.0;
+        need[b] = std::max(need[b], rows * static_cast<double>(pl.ld[c]) + static_cast<double>(kTailPadFloats));
+    }
+    total += need[0] + need[1];
+    const double N = static_cast<double>(pl.n_pro), ldN = static_cast<double>(pl.ld[L - 1]);
+    total += N * ldN;                                      // the result (its pitch is the run's when the proband cut stays in place)
+    if (!pl.final_perm.empty() && pl.final_slots.empty()) total += (N + 1.0) * ldN + static_cast<double>(kTailPadFloats);
+    double psi_p = 0.0, nn_tmp = 0.0, idx = 0.0;
+    for (const LevelStep &st : pl.steps) {
+        if (st.mode == genphi::kModeWide && !st.nn.empty())
+            psi_p = std::max(psi_p, static_cast<double>(st.nn[0].n_prev + 1) * static_cast<double>(st.nn[0].ld_prev) + static_cast<double>(kTailPadFloats));
+        if (st.stay) nn_tmp = std::max(nn_tmp, static_cast<double>(st.npad) * static_cast<double>(st.npad) + static_cast<double>(kTailPadFloats));
+        idx += 5.0 * static_cast<double>(st.n) + 2.0 * static_cast<double>(idx_pad(st)) + (st.mode == genphi::kModeSplit ? 6.0 * static_cast<double>(st.n) : 0.0)
+               + (st.mode == genphi::kModeWide ? 12.0 * static_cast<double>(st.n) : 0.0);
+    }
+    total += psi_p + nn_tmp + idx;
+    double bytes = 4.0 * total;
+    // the row-list arenas of the sparse leading cuts while they are being calibrated (sparse_levels.hip; shrunk afterwards)
+    const int S = (p->tun.sparse_k == -1 || p->popt.indices_only) ? 0 : genphi::sparse_eligible_steps(pl);
+    if (S >= 2) {
+        double nmax = 0.0;
+        for (int c = 0; c <= S; ++c) nmax = std::max(nmax, static_cast<double>(pl.cut_sizes[c]));
+        bytes += 2.0 * 8.0 * std::min(0.6 * nmax * nmax + 8.0 * nmax + 1024.0, 4.0e9);
+    }
+    return static_cast<int64_t>(bytes);
 }
 int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *nnz, int64_t *entries, int32_t cap)
 {
@@ -3051,7 +3132,7 @@ static int launch_level(genphi_plan *p, const LevelCtx &cx, const float *psi, fl
 }
 
 // ---- column panels (panel_phi.hip): a level step of a rank's panel through the same row kernels -------------
-const void *genphi::panel_tuning_create() { return new (std::nothrow) Tuning(tuning_from_env()); }
+const void *genphi::panel_tuning_create() { return new (std::nothrow) Tuning(tuning_from(nullptr)); }
 void genphi::panel_tuning_destroy(const void *t) { delete static_cast<const Tuning *>(t); }
 int genphi::panel_tuning_lds_cap(const void *t, int dflt)
 {
@@ -3643,6 +3724,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     if (e - s >= 2) {
                         const size_t lds = (2 * kSmallPitch * kSmallPitch + 3 * kSmallMax) * sizeof(float);
                         HIP_TRY(set_max_lds(reinterpret_cast<const void *>(levels_small_kernel), lds));
+                        // (the hook of every step the fused run covers, BEFORE the run is handed to the GPU: include/genphi.h promises that order)
+                        if (p->step_hook) for (int k = s + 1; k < e; ++k) p->step_hook(k, n_steps, p->step_hook_user);
                         hipLaunchKernelGGL(levels_small_kernel, dim3(1), dim3(1024), lds, p->stream, p->d_small + s, e - s,
                                            psi, static_cast<long long>(pl.ld[s]), s == 0 ? 1 : 0, p->buf[bid[e]],
                                            static_cast<long long>(pl.ld[e]), p->d_cert + p->cert_off[e], cert_threshold(p->tun));
@@ -3653,7 +3736,6 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                             HIP_TRY(hipEventRecord(p->events[e], p->stream));
                             for (int k = s; k < e; ++k) ev_after[k] = e;
                         }
-                        if (p->step_hook) for (int k = s + 1; k < e; ++k) p->step_hook(k, n_steps, p->step_hook_user);      // (the steps the fused run covers)
                         s = e - 1;
                         continue;
                     }
@@ -3887,7 +3969,9 @@ int genphi_result_to_host(genphi_plan *p, float *out)
     const size_t row_bytes = N * sizeof(float);
     const size_t tile_r = p->tun.d2h_tile_rows > 0 ? static_cast<size_t>(p->tun.d2h_tile_rows) : 256;
     const size_t tile_c = p->tun.d2h_tile_cols > 0 ? static_cast<size_t>(p->tun.d2h_tile_cols) : 8192;
-    const size_t chunk_rows = std::max<size_t>(1, (size_t(16) << 20) / row_bytes);
+    // (16 MB chunks; 4 MB for results below 2 GB, whose workers have only a few chunks each to overlap the DMA with the host copy)
+    const size_t chunk_mb = p->tun.d2h_chunk_mb > 0 ? static_cast<size_t>(p->tun.d2h_chunk_mb) : (bytes < (size_t(2) << 30) ? 4 : 16);
+    const size_t chunk_rows = std::max<size_t>(1, (chunk_mb << 20) / row_bytes);
     const size_t chunk_bytes = sym ? std::max<size_t>(tile_r * std::min(tile_c, N) * sizeof(float), 4096) : chunk_rows * row_bytes;
     bool pinned = (n_thr > 1 || sym) && !p->tun.d2h_pageable;
     // (the ring belongs to the device, not to the plan: pinning 256 MB costs 60-100 ms and unpinning them 80 ms -- per one-shot call

@@ -251,8 +251,8 @@ int genphi_panel_create(int64_t n_ind, const int64_t *ind, const int64_t *father
     } catch (const std::bad_alloc &) { delete p; return genphi_set_error(GENPHI_ERR_ALLOC, "out of memory while planning"); }
     if (rc) { delete p; return genphi_set_error(rc, err); }
     p->rank = rank; p->world = world;
-    if (const char *e = std::getenv("GENPHI_TEST_FAIL_ALLOC")) p->fail_alloc_at = std::atoi(e);
-    p->naive = std::getenv("GENPHI_PANEL_NAIVE") != nullptr;
+    if (const char *e = genphi::env_hook("GENPHI_TEST_FAIL_ALLOC")) p->fail_alloc_at = std::atoi(e);
+    p->naive = genphi::env_hook("GENPHI_PANEL_NAIVE") != nullptr;
     p->tuning = genphi::panel_tuning_create();
     const genphi::Plan &pl = p->plan;
     const int L = pl.n_levels;

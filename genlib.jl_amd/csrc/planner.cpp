@@ -813,7 +813,7 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
     // single-threaded by default: the steps are short and fresh threads cost more than they save on
     // small hosts (measured: 1 thread 0.10 s, 8 threads 0.12 s for cfg4); GENPHI_PLAN_THREADS overrides
     int n_thr = 1;
-    if (const char *e = std::getenv("GENPHI_PLAN_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(e)));
+    if (const char *e = env_hook("GENPHI_PLAN_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(e)));
     n_thr = std::min(n_thr, std::max(1, L - 1));
     if (n_thr <= 1) {
         ReuseScratch w;

@@ -166,6 +166,16 @@ void build_hub_walk(const int32_t *srcA, const int32_t *srcB, const int32_t *ord
 
 inline int64_t pitch_for(int64_t n) { return ((n + 1) + 63) / 64 * 64; }
 
+// Tuning, A/B and test hooks are GENPHI_* environment variables that the library reads ONLY when GENPHI_ENV_HOOKS=1 is set as
+// well: a shared library loaded into somebody's Julia process does not change kernels on ambient variables.  (Programmatic
+// settings: genphi_tuning, include/genphi.h.  Not gated: GENPHI_TRACE -- diagnostics on stderr -- and the memory budgets
+// GENPHI_KEEP_MB / GENPHI_SPARSE_KEEP_MB, which change no result and no kernel.)
+inline const char *env_hook(const char *name)
+{
+    static const bool on = [] { const char *e = std::getenv("GENPHI_ENV_HOOKS"); return e && std::atoi(e) != 0; }();
+    return on ? std::getenv(name) : nullptr;
+}
+
 // GENPHI_TRACE=1: wall-clock marks of the phases of a call on stderr (planner, upload, sweep): where does the host side of a call go?
 struct PhaseTrace {
     bool on;

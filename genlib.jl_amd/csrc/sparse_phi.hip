@@ -57,6 +57,7 @@
 #include <vector>
 
 #include "devcache.h"
+#include "planner.h"
 #include "../../include/genphi.h"
 
 int genphi_set_error(int code, const std::string &msg);      // genphi_hip.hip
@@ -710,10 +711,10 @@ static int sparse_impl(int64_t n_ind, const int64_t *ind, const int64_t *father,
 #define SP_GO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return bail(GENPHI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     // (GENPHI_SPARSE_STALE_CAP: the first sweep's room for entries that outlive their columns -- tests force the second sweep with it)
     int stale_cap = 1 << 16, n_stale = 0;
-    if (const char *e = std::getenv("GENPHI_SPARSE_STALE_CAP")) stale_cap = std::max(1, std::atoi(e));
+    if (const char *e = genphi::env_hook("GENPHI_SPARSE_STALE_CAP")) stale_cap = std::max(1, std::atoi(e));
     const bool timed = waves.size() <= 4096;
     size_t max_lds = 0;
-    const bool no_fused = std::getenv("GENPHI_SPARSE_NO_FUSED") != nullptr;      // (A/B and tests: the two-kernel form of a wave)
+    const bool no_fused = genphi::env_hook("GENPHI_SPARSE_NO_FUSED") != nullptr;      // (A/B and tests: the two-kernel form of a wave)
     for (const Wave &w : waves) if (w.n_new > 0 && w.n_old <= 36864) max_lds = std::max(max_lds, static_cast<size_t>((w.n_old + 3) / 4 * 4) * sizeof(float));
     for (int attempt = 0; attempt < 2; ++attempt) {               // (a second sweep only if the list of outliving entries overflowed)
         if (!st) SP_GO(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

@@ -165,23 +165,30 @@ def replicated_bytes(cut_sizes, wide_last=False, both_counts=None):
     total = need[0] + need[1] + n_last * pitch(n_last)
     if wide_last:
         total += (n_last + 1) * pitch(n_last) + tail
-    dragged = both_counts is None or any(b > 0 for b in both_counts)
-    if max(cut_sizes[:-1], default=0) > 36863 or dragged:    # block-assembly steps (WIDE, or a run kept in place): psi_p, the scatter buffer
+    dragged = both_counts is not None and any(b > 0 for b in both_counts)
+    if max(cut_sizes[:-1], default=0) > 36863 or dragged or both_counts is None:    # block-assembly steps (WIDE, or a run kept in place): psi_p, the scatter buffer
         total += max(need)
         # runs of steps may stay in place: ONE slot matrix instead of two ping-pong ones -- the planner drops the runs
         # when that needs more than 1.2 x the plain buffers and more than 4 GiB (PlanOptions::stay_mem_ratio,
-        # stay_mem_floor_bytes), so that is the bound
-        total += max((need[0] + need[1]) // 5, (1 << 30) - (need[0] + need[1]))
+        # stay_mem_floor_bytes), so that is the bound when members are known to be dragged along; with both_counts unknown only
+        # the 0.2 x term is charged (a tiny pedigree must not be charged 4 GiB).  This formula is the fallback of callers without
+        # a plan: genphi_plan_device_bytes_needed (PhiPlan.device_bytes_needed) knows the slot capacities and the result's pitch.
+        extra = (need[0] + need[1]) // 5
+        if dragged:
+            extra = max(extra, (1 << 30) - (need[0] + need[1]))
+        total += extra
     return 4 * total + 30 * sum(cut_sizes)
 
 
-def replicated_levels_fit(cut_sizes, free_bytes, dist=None, device=None, both_counts=None):
+def replicated_levels_fit(cut_sizes, free_bytes, dist=None, device=None, both_counts=None, plan_bytes=None):
     """The size test of SURVEY.md 8(e): do the replicated level matrices plus the result fit one GPU?
     With `dist` the answer is made COLLECTIVE (MIN over the ranks): ranks see different amounts of free
     memory, and a rank that went down the exchange path while its peers went down the replicated one
     would wait in a collective nobody else enters."""
     wide_last = len(cut_sizes) >= 2 and cut_sizes[-2] > 36863      # the last step reads rows of the cut before it
-    fits = replicated_bytes(cut_sizes, wide_last=wide_last, both_counts=both_counts) <= 0.92 * free_bytes
+    # (plan_bytes: what the plan itself says it will allocate -- slot matrices, the result at its pitch --, PhiPlan.device_bytes_needed)
+    need = plan_bytes if plan_bytes is not None else replicated_bytes(cut_sizes, wide_last=wide_last, both_counts=both_counts)
+    fits = need <= 0.92 * free_bytes
     if dist is not None and dist.get_world_size() > 1:
         import torch
         t = torch.tensor([1 if fits else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")

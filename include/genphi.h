@@ -83,6 +83,20 @@ int genphi_plan_create(int64_t n_ind, const int64_t *ind, const int64_t *father,
                        const int64_t *mother, int64_t n_pro, const int64_t *pro_ids,
                        genphi_plan **out);
 
+/* Tuning, A/B and test settings of a plan without the environment.  The library has ~45 knobs (README.md, "Tuning hooks": LDS budget,
+ * kernel families, in-place runs, sparse cuts, copy threads ...); none is needed in production.  They can be given as GENPHI_* environment
+ * variables -- read ONLY when GENPHI_ENV_HOOKS=1 is set too, so that a library loaded into somebody's process never changes kernels on
+ * ambient variables -- or, per plan, through a genphi_tuning: genphi_tuning_set(t, "SPARSE_K", "-1") (the hook's name with or without
+ * the GENPHI_ prefix; unknown name -> GENPHI_ERR_ARG).  genphi_plan_create_tuned(..., NULL, ...) = the defaults whatever the
+ * environment says.  The plan copies what it needs; the tuning may be destroyed right after.  No reference counterpart.        */
+typedef struct genphi_tuning genphi_tuning;
+genphi_tuning *genphi_tuning_create(void);
+int genphi_tuning_set(genphi_tuning *t, const char *name, const char *value);
+void genphi_tuning_destroy(genphi_tuning *t);
+int genphi_plan_create_tuned(int64_t n_ind, const int64_t *ind, const int64_t *father,
+                             const int64_t *mother, int64_t n_pro, const int64_t *pro_ids,
+                             const genphi_tuning *tuning, genphi_plan **out);
+
 /* Level description for the "Step i of n: a founders, b probands, c both." lines
  * (src/compute.jl:253-262 and :280-285).  cut_sizes has *n_levels entries (top founders
  * first, probands last), both_counts has *n_levels-1.  Pointers stay valid until
@@ -125,7 +139,9 @@ int genphi_plan_step_walk(const genphi_plan *plan, int32_t step, int64_t *n_rows
 /* Progress hook for the "Running step k of n (...)" lines the reference prints INSIDE its level loop (src/compute.jl:280-285, verbose):
  * cb(step, n_steps, user) is called on the calling thread right before level step `step` (0-based) is handed to the GPU, in order.
  * While a hook is set the sweep is enqueued launch by launch (never replayed from a captured graph).  cb = NULL removes it.
- * The hook must not call back into the library with the same plan.                                                              */
+ * The hook must not call back into the library with the same plan, and must not throw / raise across the C boundary (ctypes swallows
+ * a Python exception raised inside it).  A run of tiny steps goes to the GPU as ONE launch: the hooks of all its steps are called, in
+ * order, before that launch.                                                                                                     */
 typedef void (*genphi_step_fn)(int32_t step, int32_t n_steps, void *user);
 int genphi_plan_set_step_hook(genphi_plan *plan, genphi_step_fn cb, void *user);
 
@@ -142,6 +158,11 @@ int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *
 /* Device memory the plan holds right now, in bytes (level matrices, row lists of the sparse cuts, the resident result, the index
  * arrays): 0 before the first compute and after genphi_plan_release_device.  What a cache of plans budgets with.             */
 int64_t genphi_plan_device_bytes(const genphi_plan *plan);
+
+/* Host only: the device memory a full-result Float32 sweep of this plan will allocate (level matrices -- slot matrices of in-place runs
+ * included --, the result at ITS pitch, delivery buffers, index arrays, the row-list arenas of the sparse cuts): what a caller compares
+ * with the free memory of a GPU before choosing between replicated levels and column panels.                      */
+int64_t genphi_plan_device_bytes_needed(const genphi_plan *plan);
 
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
 double genphi_plan_algorithmic_bytes(const genphi_plan *plan);

@@ -2,6 +2,7 @@
 # Same-box A/B of environment switches on ONE build (boxes differ by several per cent, so only
 # numbers from one gpurun call are comparable).  usage: ab_env.sh workload "ENV=1 ..." "ENV=2 ..." ...
 # An empty string "" is the default configuration.  Three alternating repetitions.
+export GENPHI_ENV_HOOKS=1      # the library reads GENPHI_* hooks only under this gate
 WL=$1; shift
 for rep in 1 2 3; do
   for v in "$@"; do

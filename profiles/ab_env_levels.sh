@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of environment switches on ONE build, printing the first level steps' times (the sparse leading levels).
 # usage: ab_env_levels.sh workload n_levels "ENV=1 ..." "ENV=2 ..." ...   ("" = default); three alternating repetitions.
+export GENPHI_ENV_HOOKS=1      # the library reads GENPHI_* hooks only under this gate
 WL=$1; NL=$2; shift; shift
 for rep in 1 2 3; do
   for v in "$@"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: HBM bytes of the certified-rows kernel under an environment setting (one FETCH_SIZE and one WRITE_SIZE pass
 # of bench.py cfg4, one sweep).  usage: pmc_env.sh tag "ENV=1 ENV2=2"
+export GENPHI_ENV_HOOKS=1      # the library reads GENPHI_* hooks only under this gate
 TAG=$1; ENVS=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc_env/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: quick probes of the sparse leading levels (kernel stats + forced last sparse cut).
+export GENPHI_ENV_HOOKS=1      # the library reads GENPHI_* hooks only under this gate
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-r5probe}; mkdir -p "$OUT"

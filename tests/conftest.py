@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The library reads its GENPHI_* tuning / test hooks from the environment only under this gate (csrc/planner.h: env_hook); the tests steer
+# kernel families, LDS budgets, in-place runs ... through them (monkeypatch.setenv), so the gate is on for the whole session -- and for
+# the worker processes the tests start.  Set before the library is loaded: it is read once.
+os.environ["GENPHI_ENV_HOOKS"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 """Replays ONE case of tests/stress_random.py (its `case=` number) and prints the plan and which sweeps differ from the oracle.
    python tests/stress_case.py 499794305 [KEY=VALUE ...]     (extra environment knobs override the case's)"""
 import os, sys
+os.environ["GENPHI_ENV_HOOKS"] = "1"      # environment hooks are read by the library only under this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np

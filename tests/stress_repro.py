@@ -1,5 +1,6 @@
 """Replays tests/stress_random.py with the same seed until the first mismatch and dissects it."""
 import os, sys, time
+os.environ["GENPHI_ENV_HOOKS"] = "1"      # environment hooks are read by the library only under this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import genlib_jl_amd as gen

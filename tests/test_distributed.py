@@ -51,8 +51,12 @@ def test_replicated_memory_model_matches_the_allocations():
     pair = max(4 * ((a + 1) * pitch(a) + (c + 1) * pitch(c)) for a, c in zip(cuts[:-1], cuts[1:]))
     assert b > pair                                                # the old pairwise model under-estimated
     assert gdist.replicated_levels_fit(cuts, b / 0.92 + 1, both_counts=none) and not gdist.replicated_levels_fit(cuts, b / 0.92 - 1e6, both_counts=none)
-    # members dragged along (or unknown): the parent matrix of block-assembly steps and the slot matrix of in-place runs on top
-    assert 4 * (1 << 30) <= gdist.replicated_bytes(cuts) <= b + 4 * (1 << 30) + 4 * (9001 * pitch(9000) + 65536)
+    # members dragged along: the parent matrix of block-assembly steps and the slot matrix of in-place runs on top (the planner keeps
+    # runs whose slot matrices stay below 4 GiB whatever the plain buffers are); unknown: only the proportional terms -- a tiny
+    # pedigree is not charged 4 GiB (and a plan says exactly what it needs: PhiPlan.device_bytes_needed)
+    some = [1] * (len(cuts) - 1)
+    assert 4 * (1 << 30) <= gdist.replicated_bytes(cuts, both_counts=some) <= b + 4 * (1 << 30) + 4 * (9001 * pitch(9000) + 65536)
+    assert b < gdist.replicated_bytes(cuts) <= b + 4 * (9001 * pitch(9000) + 65536) + b // 4 + 1024 < 4 * (1 << 30)
     # cfg4: 3.8 GB + 2.4 GB of level matrices + the 40 GB result
     cfg4 = [24301] * 24 + [24650, 25190, 26502, 30976, 100000]
     assert 45e9 < gdist.replicated_bytes(cfg4, both_counts=[0] * 28) < 48e9
@@ -193,3 +197,16 @@ def test_survey_literal_cfg4_needs_panels_and_fits_eight_ranks():
         pp.close()
     xgmi_s = max(sent) / (7 * 153e9)
     assert 0.055 < xgmi_s < 0.066
+
+
+def test_scale_script_rehearsal():
+    """profiles/scale.sh -- the script the first 8-GPU lease runs -- rehearsed on the CPU: its launcher lines, ports and the summary
+    table, with --dry-run ranks over gloo (N = 1, 2)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out", "scale_rehearsal")
+    env = dict(os.environ, SCALE_NS="1 2", SCALE_DRY="1", SCALE_OUT=out_dir, SCALE_DRY_WORKLOAD="cfg2")
+    r = subprocess.run(["bash", os.path.join(root, "profiles", "scale.sh")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rows_n1 rc=0" in r.stdout and "rows_n2 rc=0" in r.stdout, r.stdout + r.stderr
+    assert "N=2: dry run ok" in r.stdout and "wall is max over ranks: True" in r.stdout, r.stdout

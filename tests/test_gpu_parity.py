@@ -701,15 +701,19 @@ def _resident_rows(pl, rows, chunk=32):
     return out
 
 
-def test_full_size_cfg4_oracle_row_sample(gen, oracle):
+def test_full_size_cfg4_oracle_row_sample(gen):
     """The headline configuration at FULL size (1e6 individuals / 1e5 probands / 30 generations, the bench's default workload)
-    against the ORACLE, not against another HIP kernel: every upper level step of src/compute.jl:291-299 restated in full on the
-    host (8.3e9 pair evaluations), then ~158 rows of the 1e5 x 1e5 proband matrix -- the first and the last rows of the last
-    step's work queue, rows spread over the proband order, the two corner rows -- bit for bit against the same rows of the
-    matrix the default sweep left in HBM (the 4-chunk <512, 52, 16> instantiation of the certified-rows kernel writes them:
-    each row crosses all four column chunks).  Row sums of the whole result tie the sampled sweep to the checksums that
-    test_full_size_cfg4_properties compares across kernels."""
+    against the ORACLE, not against another HIP kernel: tests/golden/cfg4_rowsample.npz holds 158 rows of the 1e5 x 1e5 proband
+    matrix as the oracle computes them -- every upper level step of src/compute.jl:291-299 restated in full on the host (8.3e9 pair
+    evaluations; tests/golden/make_rowsamples.py, 170 s on 8 cores) -- as SHA-256 per row, Float64 sums per row and per block of 4,096
+    columns.  The first and the last rows of the last step's work queue, rows spread over the proband order, three consecutive rows;
+    compared bit for bit (the hash) with the same rows of the matrix the default sweep left in HBM: sparse leading cuts, the dense
+    upper levels, the 4-chunk <512, 52, 16> instantiation of the certified-rows kernel in the last level (every row crosses all
+    four column chunks).  The same with every level dense (GENPHI_FLAG_NO_SPARSE) and as a row shard."""
+    import hashlib
     from genlib_jl_amd import synth
+    fx = np.load(os.path.join(HERE, "golden", "cfg4_rowsample.npz"))
+    rows, block = fx["rows"].astype(np.int64), int(fx["block"])
     ind, fa, mo, sex, pro = synth.random_mating(1_000_000, 100_000, 30)
     ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
     pl = gen.plan(ped, pro)
@@ -718,16 +722,25 @@ def test_full_size_cfg4_oracle_row_sample(gen, oracle):
     assert n == 100_000 and set(modes) == {1}
     desc, seg, run = pl.step_walk(len(modes) - 1)
     order = desc[:, 1].astype(np.int64)                              # output rows in work-queue order
-    assert len(order) == n and len(np.unique(order)) == n
-    rows = np.unique(np.concatenate([order[:48], order[-48:], np.linspace(0, n - 1, 59).astype(np.int64), [50_000, 50_001, 50_002]]))
-    want = oracle.Pedigree(ind, fa, mo).phi_rows(pro, rows)          # (~1.5 min on the box's cores)
-    pl.compute_device()
-    got = _resident_rows(pl, rows)
-    _assert_equal(got, want)
+    assert set(order[:48]) <= set(rows) and set(order[-48:]) <= set(rows), "the fixture samples the ends of THIS plan's work queue"
+
+    def check(got, which):
+        for k, r in enumerate(which):
+            if hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() != str(fx["sha256"][r]):
+                bs = np.array([got[k, b * block:(b + 1) * block].astype(np.float64).sum() for b in range(fx["block_sum"].shape[1])])
+                bad = np.flatnonzero(bs != fx["block_sum"][r])
+                raise AssertionError(f"row {rows[r]} differs from the oracle's: column blocks {bad.tolist()} (of {block}); row sum {got[k].astype(np.float64).sum()!r} "
+                                     f"vs {float(fx['row_sum'][r])!r}; first entries {got[k, :4]} vs {fx['head'][r, :4]} (tol {TOL})")
+
+    for no_sparse in (False, True):
+        pl.compute_device(no_sparse=no_sparse)
+        if not no_sparse:
+            assert pl.sparse_levels()[0] >= 4, pl.sparse_levels()
+        check(_resident_rows(pl, rows), range(len(rows)))
     # the same rows as a row shard of their own (shard work lists, pruned upper levels)
     k0 = int(np.searchsorted(rows, 50_000))
     assert list(rows[k0:k0 + 3]) == [50_000, 50_001, 50_002]
-    _assert_equal(pl.compute(rows=(50_000, 50_003)), want[k0:k0 + 3])
+    check(pl.compute(rows=(50_000, 50_003)), range(k0, k0 + 3))
     pl.close()
 
 
@@ -1577,3 +1590,24 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
         pl.close()
     pedj = gen.genealogy(gen.geneaJi)
     _assert_equal(gen.phi(pedj), np.array(GOLD["geneaJi"]["phi"], dtype=np.float32))
+
+
+def test_plan_memory_estimate_and_kept_blocks(gen):
+    """genphi_plan_device_bytes_needed (host only) bounds what a sweep allocates -- slot matrices of in-place runs and a result at the
+    run's pitch included (the proband cut of genea140 with a quarter of its individuals as probands stays in place) --, and released
+    plans leave their blocks to the next one (genphi_cached_bytes) until genphi_release_cached gives them back."""
+    from genlib_jl_amd import _capi
+    ped = gen.genealogy(gen.genea140)
+    ids = np.sort(np.random.default_rng(7).choice(np.asarray(ped.ind), size=len(ped.ind) // 4, replace=False))
+    for pro in (gen.pro(ped), ids):
+        pl = gen.plan(ped, pro)
+        need = pl.device_bytes_needed
+        assert pl.device_bytes == 0
+        pl.compute_device()
+        have = pl.device_bytes
+        assert 0 < have <= need <= 1.5 * have + (3 << 30), (have, need)
+        pl.close()
+    assert _capi.cached_bytes() > 0
+    _capi.release_cached()
+    assert _capi.cached_bytes() == 0
+    _assert_equal(gen.phi(ped), np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy")))

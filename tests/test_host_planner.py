@@ -6,6 +6,7 @@ import ctypes
 import io
 import os
 import re
+import sys
 from contextlib import redirect_stdout
 
 import numpy as np
@@ -453,3 +454,32 @@ def test_narrow_runs_cost_model_and_proband_cut_in_place(monkeypatch):
     assert 2 not in m5                                                                      # 140 probands: 36-57 % of a cut is new
     for k in knobs:
         monkeypatch.delenv(k, raising=False)
+
+
+def test_tuning_through_the_abi_and_the_environment_gate():
+    """Settings reach a plan through a genphi_tuning (genphi_plan_create_tuned), or through GENPHI_* environment variables -- which the
+    library reads only under GENPHI_ENV_HOOKS=1: ambient variables in somebody's process change nothing."""
+    import subprocess
+    import genlib_jl_amd as gen
+    from genlib_jl_amd import synth
+    ind, fa, mo, sex, pro = synth.random_mating(3000, 300, 8, skip_permille=100)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+    pl = gen.plan(ped, pro, tuning={})
+    default_modes = pl.step_modes()
+    pl.close()
+    assert 2 not in default_modes
+    pl = gen.plan(ped, pro, tuning={"LDS_CAP_FLOATS": 64, "GENPHI_NO_STAY": 1})      # (with or without the prefix)
+    assert 2 in pl.step_modes()                                      # rows no longer fit the LDS budget: block assembly
+    pl.close()
+    with pytest.raises(Exception):
+        gen.plan(ped, pro, tuning={"NO_SUCH_KNOB": 1})
+    code = ("import sys; sys.path.insert(0, %r); import genlib_jl_amd as gen; from genlib_jl_amd import synth; "
+            "ind, fa, mo, sex, pro = synth.random_mating(3000, 300, 8, skip_permille=100); "
+            "ped = gen.genealogy({'ind': ind, 'father': fa, 'mother': mo, 'sex': sex}); print(2 in gen.plan(ped, pro).step_modes())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GENPHI_")}
+    env["GENPHI_LDS_CAP_FLOATS"] = "64"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == "False", out.stdout + out.stderr      # the variable alone: ignored
+    env["GENPHI_ENV_HOOKS"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == "True", out.stdout + out.stderr
