@@ -440,6 +440,7 @@ def main():
     ap.add_argument("--no-d2h", action="store_true", help="skip the device-to-host copy of the end_to_end block")
     ap.add_argument("--no-others", action="store_true",
                     help="default run (cfg4, 1 GPU): do not measure the other BASELINE.json configurations (cfg2, cfg3, cfg3s, cfg5) for `other_workloads`")
+    ap.add_argument("--no-call-wall", action="store_true", help="do not time one-shot gen.phi calls (profiling runs: only the sweeps of ONE plan in the process)")
     ap.add_argument("--no-sparse", action="store_true", help="A/B: every level as a dense matrix (GENPHI_FLAG_NO_SPARSE)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -727,7 +728,7 @@ def main():
                                         "bandwidth figure); `real_traffic_frac`: measured HBM traffic")
         if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
-        if world == 1 and not f64 and args.kernel == 0 and not args.no_sparse:
+        if world == 1 and not f64 and args.kernel == 0 and not args.no_sparse and not args.no_call_wall:
             # a one-shot call through the drop-in API (result left resident when it is too large to copy twice within the run)
             out["end_to_end"]["call_wall"] = call_walls(ped, pro, local_rank, with_d2h=n * n * 4 <= (2 << 30), reps=3 if n <= 20000 else 1)
         if args.workload == "cfg4" and world == 1 and not f64 and args.kernel == 0 and not args.no_others and not args.no_sparse and not ab_hooks:

@@ -2413,10 +2413,12 @@ int64_t genphi_plan_device_bytes_needed(const genphi_plan *p)
     // what upload_plan / ensure_level_buffers / genphi_compute_device allocate for a full-result Float32 sweep of this plan
     double need[2] = {0.0, 0.0}, total = 0.0;
     int b = 0;
-    for (int c = 0; c + 1 < L; ++c) {
-        if (c >= 1) b = pl.steps[c - 1].stay ? b : 1 - b;
+    for (int c = 0; c + 1 < L; ++c) {                      // (as ensure_level_buffers: each buffer serves the sweep with in-place steps AND
+        if (c >= 1) b = pl.steps[c - 1].stay ? b : 1 - b;  //  the plain alternation of the per-entry sweep)
         const double rows = static_cast<double>(pl.steps[c].src_slots ? pl.steps[c].P : pl.cut_sizes[c]) + 1.0;
-        need[b] = std::max(need[b], rows * static_cast<double>(pl.ld[c]) + static_cast<double>(kTailPadFloats));
+        const double fl = rows * static_cast<double>(pl.ld[c]) + static_cast<double>(kTailPadFloats);
+        need[b] = std::max(need[b], fl);
+        need[c & 1] = std::max(need[c & 1], fl);
     }
     total += need[0] + need[1];
     const double N = static_cast<double>(pl.n_pro), ldN = static_cast<double>(pl.ld[L - 1]);
@@ -3510,7 +3512,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         const int S = p->tun.sparse_k == -1 ? 0 : genphi::sparse_eligible_steps(pl);
         if (S >= 2) {
             std::vector<genphi::SparseStepDev> dev(S);
-            for (int s = 0; s < S; ++s) dev[s] = genphi::SparseStepDev{p->dsteps[s].srcA, p->dsteps[s].srcB, p->dsteps[s].ord};
+            for (int s = 0; s < S; ++s) dev[s] = genphi::SparseStepDev{p->dsteps[s].srcA, p->dsteps[s].srcB, p->dsteps[s].ord, p->dsteps[s].work};
             genphi::SparseTuning stn;
             stn.force_k = p->tun.sparse_k;
             if (p->tun.sparse_permille > 0) stn.max_permille = p->tun.sparse_permille;

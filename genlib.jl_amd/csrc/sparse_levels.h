@@ -35,6 +35,7 @@ constexpr int kSparseMaxMembers = 65535;      // columns are kept as 16-bit word
 
 struct SparseStepDev {                        // device index arrays of level step s (per member of cut s+1)
     const int *srcA, *srcB, *ord;
+    const int *work;                          // the planner's row order of the step (rows that share sources adjacent), or nullptr
 };
 
 struct SparseTuning {
@@ -43,7 +44,7 @@ struct SparseTuning {
     int force_k = -2;          // test / A-B hook: -2 = by calibration; -1 = never sparse; k >= 0: cuts 0..k sparse whatever the counts say
                                // (clamped to what is eligible)
     int min_cut = 1536;        // ... and only when some cut of the sparse run has at least this many members (narrower levels are launch-bound)
-    int chunk_cols = 8192;     // columns per workgroup of the sparse -> dense step
+    int chunk_cols = 12288;    // columns per workgroup of the sparse -> dense step (cfg4, same box: 0.62 ms at 8192, 0.56 at 12288, 0.79 at 4096)
     int classes = -1;          // a launch per class of row lengths: -1 = where the rows of a cut differ much in length, 1 / 0 = always / never (A/B hook)
 };
 

@@ -64,6 +64,7 @@ struct SpArgs {
     const uint2 *mt;              //   cut s+2 with A_i = p and a second parent B
     unsigned *fm_out;             // per member of cut s+2
     const int *rows;              // the members this launch computes (nullptr: member = workgroup index)
+    int remap;                    // rows in the planner's work order: consecutive ones on one XCD (not for rows sorted by length: the long ones would share one)
     unsigned *rnz_out;            // (calibration run) non-zero entries of every row of Psi_{s+1}
     int wp;                       // bitmap words in LDS: workgroup size x an odd number
     int cap;                      // entries of one row of Psi_{s+1} the LDS holds
@@ -92,6 +93,14 @@ __global__ void __launch_bounds__(256) sparse_identity_kernel(uint2 *ent, uint2 
     if (k < n_stat) stat[k] = 0u;
 }
 
+// consecutive work items on one XCD (workgroups b and b + 8 share an XCD and its L2): rows that share source lists then find them
+// in that L2.  Bijective for any number of workgroups.
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 struct SrcRows {
     unsigned offA, lenA, offB, total;
 };
@@ -108,9 +117,11 @@ __device__ __forceinline__ SrcRows src_rows(const SpArgs &a, int A, int B)
 // entries of every thread stay in registers between the passes of the row-list step (most rows have no more); the rest is read again.
 constexpr int kBatch = 4;
 
-template <int NT>
+constexpr int kBatchDense = 16;      // the sparse -> dense step: one pass over the lists, so as many loads in flight as a thread has entries
+
+template <int NT, int KB = kBatch>
 struct EntryCache {
-    uint2 en[kBatch];
+    uint2 en[KB];
 };
 
 __device__ __forceinline__ uint2 load_entry(const SpArgs &a, const SrcRows &r, unsigned e)
@@ -118,26 +129,26 @@ __device__ __forceinline__ uint2 load_entry(const SpArgs &a, const SrcRows &r, u
     return a.ent_in[e < r.lenA ? r.offA + e : r.offB + (e - r.lenA)];
 }
 
-template <int NT>
-__device__ __forceinline__ void load_first(const SpArgs &a, const SrcRows &r, int tid, EntryCache<NT> &c)
+template <int NT, int KB>
+__device__ __forceinline__ void load_first(const SpArgs &a, const SrcRows &r, int tid, EntryCache<NT, KB> &c)
 {
     if (r.total == 0u) return;
 #pragma unroll
-    for (int b = 0; b < kBatch; ++b) c.en[b] = load_entry(a, r, min(static_cast<unsigned>(tid + b * NT), r.total - 1u));
+    for (int b = 0; b < KB; ++b) c.en[b] = load_entry(a, r, min(static_cast<unsigned>(tid + b * NT), r.total - 1u));
 }
 
-template <int NT, class F>
-__device__ __forceinline__ void for_each_entry(const SpArgs &a, const SrcRows &r, int tid, const EntryCache<NT> &c, F &&f)
+template <int NT, int KB, class F>
+__device__ __forceinline__ void for_each_entry(const SpArgs &a, const SrcRows &r, int tid, const EntryCache<NT, KB> &c, F &&f)
 {
 #pragma unroll
-    for (int b = 0; b < kBatch; ++b)
+    for (int b = 0; b < KB; ++b)
         if (static_cast<unsigned>(tid + b * NT) < r.total) f(c.en[b].x, c.en[b].y);
-    for (unsigned e0 = tid + kBatch * NT; e0 < r.total; e0 += kBatch * NT) {
-        uint2 en[kBatch];
+    for (unsigned e0 = tid + KB * NT; e0 < r.total; e0 += KB * NT) {
+        uint2 en[KB];
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) en[b] = load_entry(a, r, min(e0 + b * NT, r.total - 1u));
+        for (int b = 0; b < KB; ++b) en[b] = load_entry(a, r, min(e0 + b * NT, r.total - 1u));
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b)
+        for (int b = 0; b < KB; ++b)
             if (e0 + b * NT < r.total) f(en[b].x, en[b].y);
     }
 }
@@ -187,20 +198,21 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     __shared__ unsigned off_slot;
     __shared__ int wsum[NT / 64 + 1];
     const int tid = threadIdx.x;
-    const int i = a.rows ? a.rows[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int w = a.remap ? xcd_remap(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x);
+    const int i = a.rows ? a.rows[w] : w;
     const int A = a.srcA[i], B = a.srcB[i];
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
     EntryCache<NT> ec;
-    load_first<NT>(a, r, tid, ec);
+    load_first(a, r, tid, ec);
     const uint2 place = a.fixed ? a.rowd_out[i] : make_uint2(0u, 0u);
     const unsigned fm_i = (new_i && A != none && B != none) ? a.fm_in[i] : 0u;
     const int mt0 = a.mt_off[i], mt1 = a.mt_off[i + 1];
     for (int w = tid; w < a.wp; w += NT) bm[w] = 0u;
     __syncthreads();
     // pass 1: which columns
-    for_each_entry<NT>(a, r, tid, ec, [&](unsigned c, unsigned) { atomicOr(&bm[c >> 5], 1u << (c & 31u)); });
+    for_each_entry(a, r, tid, ec, [&](unsigned c, unsigned) { atomicOr(&bm[c >> 5], 1u << (c & 31u)); });
     if (new_i && tid == 0) atomicOr(&bm[i >> 5], 1u << (i & 31));
     __syncthreads();
     // every thread owns T consecutive bitmap words (T odd: no bank conflicts between the lanes)
@@ -229,7 +241,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     __syncthreads();
     // pass 2: the values, in units of 2^-(2s+3)
     const unsigned wi = new_i ? 1u : 2u;
-    for_each_entry<NT>(a, r, tid, ec, [&](unsigned c, unsigned m) {
+    for_each_entry(a, r, tid, ec, [&](unsigned c, unsigned m) {
         if (new_i && c == static_cast<unsigned>(i)) return;               // the diagonal of a new member is not a sum of this kind
         const int at = pre[c >> 5] + __popc(bm[c >> 5] & ((1u << (c & 31u)) - 1u));
         atomicAdd(&vals[at], m * wi);
@@ -306,7 +318,13 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
 {
     extern __shared__ unsigned acc[];
     const int tid = threadIdx.x;
-    const int i = blockIdx.x / a.n_chunks, chunk = blockIdx.x - i * a.n_chunks;
+    // Workgroups b, b + 8, b + 16 ... run on the same XCD: the chunks of one row go there back to back, and so do the rows that follow
+    // it in the planner's work order (siblings adjacent, families chained along shared mothers) -- the lists of a row's sources are then
+    // read from HBM once per XCD visit instead of once per chunk and child (measured on cfg4: 1.98 GB of HBM reads for 0.33 GB of lists).
+    const int grp = blockIdx.x / (8 * a.n_chunks), rest = blockIdx.x - grp * 8 * a.n_chunks;
+    const int w = grp * 8 + (rest & 7), chunk = rest >> 3;
+    if (w > a.n) return;
+    const int i = w < a.n ? (a.rows ? a.rows[w] : w) : a.n;
     const int c0 = chunk * a.chunk_cols;
     if (i >= a.n) {                                        // the "none" row: zeros over the whole pitch
         const int c1 = static_cast<int>(min(static_cast<long long>(c0) + a.chunk_cols, a.ld));
@@ -323,12 +341,12 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     const SrcRows r = src_rows(a, A, B);
     const bool diag_here = new_i && i >= c0 && i < c1;
     const unsigned fm_i = (diag_here && A != none && B != none) ? a.fm_in[i] : 0u;
+    EntryCache<256, kBatchDense> ec;
+    load_first(a, r, tid, ec);                             // (in flight while the accumulators are cleared)
     for (int j = 4 * tid; j < c1 - c0; j += 1024) *reinterpret_cast<uint4 *>(acc + j) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const unsigned wi = new_i ? 1u : 2u;
-    EntryCache<256> ec;
-    load_first<256>(a, r, tid, ec);
-    for_each_entry<256>(a, r, tid, ec, [&](unsigned cu, unsigned m) {
+    for_each_entry(a, r, tid, ec, [&](unsigned cu, unsigned m) {
         const int c = static_cast<int>(cu);
         if (c < c0 || c >= c1 || (new_i && c == i)) return;
         atomicAdd(&acc[c - c0], m * wi);
@@ -564,6 +582,7 @@ static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int
     if (n_rows <= 0) return GENPHI_OK;
     SpArgs a = args_for(sl, s);
     a.rows = rows;
+    a.remap = (rows != nullptr && rows == sl->dev[s].work) ? 1 : 0;
     a.cap = cap;
     a.wp = wp_for(a.n, wide ? 256 : 64);
     const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
@@ -701,8 +720,8 @@ int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std:
     // several launches cost their tails (cfg4: +12 % on its two largest list steps) -- and a launch per class of lengths when they are
     // not (a real genealogy: the longest row of genea140's cut 8 is 12 x the average; -11 % over its list steps).  classes = 1 / 0 force.
     const bool skewed = static_cast<long long>(sl->max_row[s + 1]) * sl->n_of[s + 1] > 3ll * sl->nnz[s + 1];
-    if (sl->tun.classes == 0 || (sl->tun.classes < 0 && !skewed))
-        return launch_rows(sl, s, nullptr, sl->n_of[s + 1], cap_max, sl->n_ent[s] > 192ll * sl->n_of[s], stream, err);
+    if (sl->tun.classes == 0 || (sl->tun.classes < 0 && !skewed))      // (in the planner's work order: rows that share sources adjacent)
+        return launch_rows(sl, s, sl->dev[s].work, sl->n_of[s + 1], cap_max, sl->n_ent[s] > 192ll * sl->n_of[s], stream, err);
     // rows of more than 1024 entries, of more than 256, the rest: each launch with the LDS its rows need (a launch sized for the
     // longest row of a real genealogy leaves room for four wavefronts per CU)
     rc = launch_rows(sl, s, ord + cl[0], cl[1] - cl[0], cap_max, true, stream, err);
@@ -722,7 +741,8 @@ int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long
     a.chunk_cols = static_cast<int>(((width + row_chunks - 1) / row_chunks + 255) / 256 * 256);
     a.n_chunks = static_cast<int>((std::max(ld, width) + a.chunk_cols - 1) / a.chunk_cols);
     const size_t lds = static_cast<size_t>(a.chunk_cols) * sizeof(unsigned);
-    hipLaunchKernelGGL(sparse_dense_kernel, dim3(static_cast<unsigned>((a.n + 1)) * a.n_chunks), dim3(256), lds, stream, a);
+    a.rows = sl->dev[sl->k].work;
+    hipLaunchKernelGGL(sparse_dense_kernel, dim3(static_cast<unsigned>((a.n + 1 + 7) / 8 * 8) * a.n_chunks), dim3(256), lds, stream, a);
     SP_TRY(hipGetLastError());
     return GENPHI_OK;
 }

@@ -27,7 +27,7 @@ def csrc_sha16(root=None):
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(root, "genlib.jl_amd", "csrc")
-    for name in ("genphi_hip.hip", "planner.cpp", "planner.h", "panel_launch.h"):
+    for name in ("genphi_hip.hip", "sparse_levels.hip", "sparse_levels.h", "planner.cpp", "planner.h", "panel_launch.h"):
         h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -59,11 +59,20 @@ try:
 except Exception:
     T = {}
 KERNELS = ("level_", "levels_small", "rows_compact", "rows_avg", "drag_rows", "transpose_block", "transpose_slots", "slots_scatter", "slots_clear",
-           "copy_block", "pad_zero", "colperm", "group_split")
+           "copy_block", "pad_zero", "colperm", "group_split", "sparse_step", "sparse_dense", "sparse_identity")
 rows, tot, sweeps, steps = [], 0.0, 0, 0
+# (the first sparse_identity_kernel of a process starts the CALIBRATION run of the plan's sparse cuts, sparse_levels.hip: its list
+# steps are not part of a sweep and are left out)
+n_sparse_ident = 0
 for k in F:
     name = F[k]["name"]
     if not any(t in name for t in KERNELS) or k not in W:
+        continue
+    if "sparse_identity_kernel" in name:
+        n_sparse_ident += 1
+        if n_sparse_ident >= 2:
+            sweeps += 1
+    if n_sparse_ident == 1 and "sparse_" in name:
         continue
     m = re.search(r"\(anonymous namespace\)::([A-Za-z_0-9]+(?:<[^>]*>)?)\(", name)      # (the argument list names the namespace again)
     short = (m.group(1) if m else name.split("(")[0]).replace(", ", ",")
@@ -97,6 +106,6 @@ json.dump({"workload": wl, "tag": tag, "csrc_sha16": csrc_sha16(root), "sweeps_p
            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) and --pmc WRITE_SIZE in separate passes, "
                      "KiB -> bytes, summed over every kernel of the profiled gen.phi sweeps; per launch = per level step "
                      "(a WIDE level step is several kernels)",
-           "csrc_sha16_note": "fingerprint of genphi_hip.hip, planner.cpp, planner.h, panel_launch.h (the dense path) as collected"},
+           "csrc_sha16_note": "fingerprint of genphi_hip.hip, sparse_levels.hip / .h, planner.cpp, planner.h, panel_launch.h as collected"},
           open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
 print(f"{len(rows)} dispatches, {sweeps} sweeps, {tot / sweeps / 1e9:.2f} GB per sweep" + (f", {per_step / 1e9:.3f} GB per level step" if per_step else ""))
