@@ -75,6 +75,8 @@ struct SpArgs {
     long long ld;
     int width, chunk_cols, n_chunks;
     float unit_out;               // 2^-(2s+3): one integer unit of cut s+1
+    const int *slot;              // the cut written is stored BY SLOT (a step that stays in place, planner.h: LevelStep::stay): row and column of
+    int zrow;                     //   member i = slot[i]; nullptr: compactly (row = column = i).  zrow: the all-zero "none" row (n, or the slot capacity P)
 };
 
 // Y_0 = (1/2 I) A^T: row p is the children list of p itself; fm_0[i] = Psi_0[A_i][B_i] = 1/2 only when a member's two parents are
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     const int c0 = chunk * a.chunk_cols;
     if (i >= a.n) {                                        // the "none" row: zeros over the whole pitch
         const int c1 = static_cast<int>(min(static_cast<long long>(c0) + a.chunk_cols, a.ld));
-        float *orow = a.out + static_cast<long long>(a.n) * a.ld;
+        float *orow = a.out + static_cast<long long>(a.zrow) * a.ld;
         const f4_t z = {0.f, 0.f, 0.f, 0.f};
         for (int j = c0 + 4 * tid; j < c1; j += 1024) __builtin_nontemporal_store(z, reinterpret_cast<f4_t *>(orow + j));
         return;
@@ -339,7 +341,8 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
-    const bool diag_here = new_i && i >= c0 && i < c1;
+    const int si = a.slot ? a.slot[i] : i;                 // row / column of member i in the matrix written
+    const bool diag_here = new_i && si >= c0 && si < c1;
     const unsigned fm_i = (diag_here && A != none && B != none) ? a.fm_in[i] : 0u;
     EntryCache<256, kBatchDense> ec;
     load_first(a, r, tid, ec);                             // (in flight while the accumulators are cleared)
@@ -347,14 +350,15 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     __syncthreads();
     const unsigned wi = new_i ? 1u : 2u;
     for_each_entry(a, r, tid, ec, [&](unsigned cu, unsigned m) {
-        const int c = static_cast<int>(cu);
-        if (c < c0 || c >= c1 || (new_i && c == i)) return;
+        if (new_i && cu == static_cast<unsigned>(i)) return;
+        const int c = a.slot ? a.slot[cu] : static_cast<int>(cu);
+        if (c < c0 || c >= c1) return;
         atomicAdd(&acc[c - c0], m * wi);
     });
     __syncthreads();
-    if (diag_here && tid == 0) acc[i - c0] = a.half_out + 2u * fm_i;
+    if (diag_here && tid == 0) acc[si - c0] = a.half_out + 2u * fm_i;
     __syncthreads();
-    float *orow = a.out + static_cast<long long>(i) * a.ld + c0;
+    float *orow = a.out + static_cast<long long>(si) * a.ld + c0;
     for (int j = 4 * tid; j < c1 - c0; j += 1024) {
         const uint4 u = *reinterpret_cast<const uint4 *>(acc + j);
         const f4_t v = {static_cast<float>(u.x) * a.unit_out, static_cast<float>(u.y) * a.unit_out, static_cast<float>(u.z) * a.unit_out,
@@ -379,6 +383,10 @@ struct SparseLevels {
     std::vector<const unsigned *> ch;
     std::vector<const uint2 *> mt;
     std::vector<int> n_ch;           // entries of ch per step
+    std::vector<const int *> slot;   // per step that stays in place: slot of every member of the cut it writes (else nullptr)
+    std::vector<int> zrow;           // per step: the all-zero "none" row of the matrix it writes
+    std::vector<double> dense_ms;    // per step: estimated time of the step as the dense plan would run it (row kernels, block assembly, in place)
+    std::vector<double> out_bytes;   // per step: bytes of the dense matrix the sparse -> dense step would write in its place
     uint2 *ent[2] = {nullptr, nullptr};
     uint2 *rowd_blob = nullptr;      // row descriptors of cuts 0..S-1, written by the calibration run and kept
     std::vector<uint2 *> rowd;
@@ -408,8 +416,10 @@ int sparse_eligible_steps(const Plan &plan)
     for (int s = 0; s + 1 < n_steps; ++s) {                // (the proband step keeps its row kernel: proband order, row shards)
         const LevelStep &st = plan.steps[s];
         if (s + 1 > kSparseMaxLevel) break;
-        if (st.mode == kModeWide || st.stay || st.src_slots) break;
+        // (any kernel family of the dense plan: a list step needs the sources of the members only, and the step that writes the first
+        // dense matrix writes it the way the plan stores that cut -- compactly, or by slot when the step stays in place)
         if (st.n >= kSparseMaxMembers || st.n_prev >= kSparseMaxMembers || st.n < 1 || st.n_prev < 1) break;
+        if (st.stay && st.P >= kSparseMaxMembers) break;
         ++S;
     }
     return S;
@@ -472,6 +482,7 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
         }
         sl->n_ch.push_back(off[n_prev]);
         total += al256(off.size() * sizeof(int)) + al256(ch.size() * sizeof(unsigned)) + al256(moff.size() * sizeof(int)) + al256(mt.size() * sizeof(uint2));
+        if (st.stay) total += al256(st.out_slots.size() * sizeof(int));
     }
     sl->n_ent[0] = sl->n_ch[0];
     trace.mark("  sparse: children, mates (host)");
@@ -479,7 +490,7 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     if (cached_malloc(reinterpret_cast<void **>(&sl->blob), total) != hipSuccess) return fail("hipMalloc (children lists) failed");
     std::vector<char> host(total, 0);
     size_t o = 0;
-    sl->ch_off.resize(S); sl->ch.resize(S); sl->mt_off.resize(S); sl->mt.resize(S);
+    sl->ch_off.resize(S); sl->ch.resize(S); sl->mt_off.resize(S); sl->mt.resize(S); sl->slot.assign(S, nullptr); sl->zrow.assign(S, 0);
     auto put = [&](const void *src, size_t bytes) -> const char * {
         std::memcpy(host.data() + o, src, bytes);
         const char *d = sl->blob + o;
@@ -491,6 +502,23 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
         sl->ch[s] = reinterpret_cast<const unsigned *>(put(chs[s].data(), chs[s].size() * sizeof(unsigned)));
         sl->mt_off[s] = reinterpret_cast<const int *>(put(moffs[s].data(), moffs[s].size() * sizeof(int)));
         sl->mt[s] = reinterpret_cast<const uint2 *>(put(mts[s].data(), mts[s].size() * sizeof(uint2)));
+        const LevelStep &st = plan.steps[s];
+        if (st.stay) sl->slot[s] = reinterpret_cast<const int *>(put(st.out_slots.data(), st.out_slots.size() * sizeof(int)));
+        // (a cut stored by slot -- written by a step that stays in place, or the compactly written entry cut of such a run -- has its
+        // "none" row at the slot capacity P = its pitch)
+        sl->zrow[s] = (st.stay || (s + 1 < static_cast<int>(plan.steps.size()) && plan.steps[s + 1].src_slots)) ? static_cast<int>(plan.ld[s + 1]) : static_cast<int>(st.n);
+        // what the step costs as the dense plan runs it, in matrix entries moved (the planner's own cost model, planner.cpp): a row-kernel
+        // level reads and writes whole matrices; block assembly moves the new members' blocks and, unless it stays in place, the dragged block
+        const double n = static_cast<double>(st.n), np = static_cast<double>(st.n_prev), d = static_cast<double>(st.n_dragged), nu = n - d;
+        const double q = static_cast<double>(st.parents.size());
+        const double nn = 2.0 * q * q + 1.5 * nu * q + nu * nu;
+        double entries = np * np + n * n, fixed = 0.008;
+        if (st.mode == kModeWide) {
+            entries = st.stay ? nn + nu * nu + 3.5 * nu * d : nn + (d + 2.0 * nu) * np + n * d + 2.0 * nu * d;
+            fixed = 0.045;
+        }
+        sl->dense_ms.push_back(4.0 * entries / 4.6e9 + fixed);
+        sl->out_bytes.push_back(4.0 * n * static_cast<double>(st.width));
     }
     if (hipMemcpyAsync(sl->blob, host.data(), total, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return fail("upload of the children lists failed");
@@ -601,14 +629,9 @@ static double t_list_step(const SparseLevels *sl, int s)
 }
 static double t_dense_from_lists(const SparseLevels *sl, int k)
 {
-    const double n = sl->n_of[k + 1];
-    return 4.0 * n * n / 5.0e9 + 16.0 * static_cast<double>(sl->n_ent[k]) / 3.5e9 + 0.008;
+    return sl->out_bytes[k] / 5.0e9 + 16.0 * static_cast<double>(sl->n_ent[k]) / 3.5e9 + 0.008;
 }
-static double t_dense_step(const SparseLevels *sl, int s)
-{
-    const double a = sl->n_of[s], b = sl->n_of[s + 1];
-    return 4.0 * (a * a + b * b) / 4.6e9 + 0.008;
-}
+static double t_dense_step(const SparseLevels *sl, int s) { return sl->dense_ms[s]; }
 
 int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &err)
 {
@@ -742,6 +765,8 @@ int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long
     a.n_chunks = static_cast<int>((std::max(ld, width) + a.chunk_cols - 1) / a.chunk_cols);
     const size_t lds = static_cast<size_t>(a.chunk_cols) * sizeof(unsigned);
     a.rows = sl->dev[sl->k].work;
+    a.slot = sl->slot[sl->k];
+    a.zrow = sl->zrow[sl->k];
     hipLaunchKernelGGL(sparse_dense_kernel, dim3(static_cast<unsigned>((a.n + 1 + 7) / 8 * 8) * a.n_chunks), dim3(256), lds, stream, a);
     SP_TRY(hipGetLastError());
     return GENPHI_OK;

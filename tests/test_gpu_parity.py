@@ -1590,6 +1590,25 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
         pl.close()
     pedj = gen.genealogy(gen.geneaJi)
     _assert_equal(gen.phi(pedj), np.array(GOLD["geneaJi"]["phi"], dtype=np.float32))
+    # sparse cuts that reach into a run of steps that stay in place (persistent slots): the first dense matrix is then written BY SLOT,
+    # or compactly as the entry cut of the run, and the in-place steps go on from it
+    monkeypatch.setenv("GENPHI_STAY_NARROW_MIN", "0")
+    monkeypatch.setenv("GENPHI_STAY_OVERHEAD_K", "0")
+    monkeypatch.setenv("GENPHI_STAY_MEM_PCT", "100000")
+    n_by_slot = 0
+    for args, kw in (((6000, 400, 12), dict(skip_permille=150)), ((9000, 300, 16), dict(skip_permille=400, seed=3)), ((30000, 2000, 14), dict(skip_permille=30))):
+        ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
+        ped4 = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex})
+        want = oracle.Pedigree(ind, fa, mo).phi(pro)
+        for force in ("1", "2", "3", "5", "8"):
+            monkeypatch.setenv("GENPHI_SPARSE_K", force)
+            pl = gen.plan(ped4, pro)
+            _assert_equal(pl.compute(), want)
+            k = pl.sparse_levels()[0]
+            n_by_slot += int(k >= 1 and bool(pl.step_slots(k)[0] & 1))        # step k stays in place: cut k + 1 written by slot
+            _assert_equal(pl.compute(no_sparse=True), want)
+            pl.close()
+    assert n_by_slot >= 3, n_by_slot
 
 
 def test_plan_memory_estimate_and_kept_blocks(gen):
