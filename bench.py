@@ -728,13 +728,14 @@ def main():
                                         "bandwidth figure); `real_traffic_frac`: measured HBM traffic")
         if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
+        if world == 1:
+            pl.close()                                     # (the measurements below make plans of their own: this one's memory first)
+            pl = None
         if world == 1 and not f64 and args.kernel == 0 and not args.no_sparse and not args.no_call_wall:
             # a one-shot call through the drop-in API (result left resident when it is too large to copy twice within the run)
             out["end_to_end"]["call_wall"] = call_walls(ped, pro, local_rank, with_d2h=n * n * 4 <= (2 << 30), reps=3 if n <= 20000 else 1)
         if args.workload == "cfg4" and world == 1 and not f64 and args.kernel == 0 and not args.no_others and not args.no_sparse and not ab_hooks:
             # the other BASELINE.json configurations in the same process (each a few ms per sweep): driver-timed evidence for them
-            pl.close()
-            pl = None
             others = {}
             for w in ("cfg2", "cfg3", "cfg3s", "cfg5"):
                 try:

@@ -46,23 +46,65 @@ function flatten(pedigree::GenLib.Pedigree)
     ind, father, mother, sex
 end
 
+# The plans of the last calls, per pedigree: the host prologue of GenLib.phi (src/compute.jl:236-262: levelisation, cut sets, index copy)
+# depends on (pedigree, probandIDs) alone, so a repeated call skips planning, upload and the calibration of the sparse cuts and pays the
+# sweep and the copy (genea140: 6.2 ms for a first call, 0.7 ms for a repeated one).  A plan that holds more than PLAN_CACHE_DEVICE_BYTES
+# of device memory is destroyed at the end of its call.  `release_cached()` drops the plans and what the library itself keeps.
+const PLAN_CACHE_ENTRIES = 4
+const PLAN_CACHE_DEVICE_BYTES = 2 << 30
+const plan_cache = WeakKeyDict{GenLib.Pedigree, Vector{Tuple{Vector{Int}, Int, Ptr{Cvoid}}}}()   # (probandIDs, device, plan), least recent first
+
+destroy_plan(plan::Ptr{Cvoid}) = ccall((:genphi_plan_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), plan)
+
+function release_cached()
+    for entries in values(plan_cache), (_, _, plan) in entries
+        destroy_plan(plan)
+    end
+    empty!(plan_cache)
+    ccall((:genphi_release_cached, libgenphi), Cvoid, ())      # device blocks, streams and pinned staging the library keeps between calls
+end
+
+# tuning: nothing (the library's defaults; GENPHI_* environment hooks only under GENPHI_ENV_HOOKS=1) or settings for this plan alone,
+# e.g. Dict("SPARSE_K" => -1) (genphi_plan_create_tuned; such plans are not cached)
+function create_plan(pedigree::GenLib.Pedigree, probandIDs::Vector{Int}, tuning)
+    ind, father, mother, _ = flatten(pedigree)
+    plan = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ind father mother probandIDs begin
+        if isnothing(tuning)
+            check(ccall((:genphi_plan_create, libgenphi), Cint,
+                        (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
+                        length(ind), ind, father, mother, length(probandIDs), probandIDs, plan))
+        else
+            t = ccall((:genphi_tuning_create, libgenphi), Ptr{Cvoid}, ())
+            try
+                for (name, value) in tuning
+                    check(ccall((:genphi_tuning_set, libgenphi), Cint, (Ptr{Cvoid}, Cstring, Cstring), t, string(name), string(value)))
+                end
+                check(ccall((:genphi_plan_create_tuned, libgenphi), Cint,
+                            (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+                            length(ind), ind, father, mother, length(probandIDs), probandIDs, t, plan))
+            finally
+                ccall((:genphi_tuning_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), t)
+            end
+        end
+    end
+    plan[]
+end
+
 """
     phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
-        verbose::Bool = false, compute::Bool = true, device::Integer = -1)
+        verbose::Bool = false, compute::Bool = true, device::Integer = -1, tuning = nothing)
 
 Square `Matrix{Float32}` of pairwise kinship coefficients between probands, bit-identical to
 `GenLib.phi`, computed on an MI355X.
 """
 function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(pedigree);
-             verbose::Bool = false, compute::Bool = true, device::Integer = -1)
-    ind, father, mother, _ = flatten(pedigree)
-    n = length(ind)
-    plan = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve ind father mother probandIDs begin
-        check(ccall((:genphi_plan_create, libgenphi), Cint,
-                    (Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
-                    n, ind, father, mother, length(probandIDs), probandIDs, plan))
-    end
+             verbose::Bool = false, compute::Bool = true, device::Integer = -1, tuning = nothing)
+    entries = get!(() -> Tuple{Vector{Int}, Int, Ptr{Cvoid}}[], plan_cache, pedigree)
+    hit = isnothing(tuning) ? findfirst(e -> e[2] == device && e[1] == probandIDs, entries) : nothing
+    plan = Ref{Ptr{Cvoid}}(isnothing(hit) ? create_plan(pedigree, probandIDs, tuning) : entries[hit][3])
+    isnothing(hit) || deleteat!(entries, hit)              # (re-inserted as the most recent one below, if the call succeeds)
+    keep = false
     try
         nlev = Ref{Int32}(0); sizes = Ref{Ptr{Int64}}(C_NULL); both = Ref{Ptr{Int64}}(C_NULL)
         check(ccall((:genphi_plan_levels, libgenphi), Cint,
@@ -88,9 +130,17 @@ function phi(pedigree::GenLib.Pedigree, probandIDs::Vector{Int} = GenLib.pro(ped
         GC.@preserve Φ hook check(ccall((:genphi_compute_f32, libgenphi), Cint,
                                    (Ptr{Cvoid}, Ptr{Float32}, Ptr{GenphiOpts}, Ptr{Cvoid}),
                                    plan[], Φ, opts, C_NULL))
+        isnothing(hook) || check(ccall((:genphi_plan_set_step_hook, libgenphi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), plan[], C_NULL, C_NULL))
+        if isnothing(tuning) && ccall((:genphi_plan_device_bytes, libgenphi), Int64, (Ptr{Cvoid},), plan[]) <= PLAN_CACHE_DEVICE_BYTES
+            push!(entries, (copy(probandIDs), Int(device), plan[]))
+            keep = true
+            while length(entries) > PLAN_CACHE_ENTRIES
+                destroy_plan(popfirst!(entries)[3])
+            end
+        end
         return Φ
     finally
-        ccall((:genphi_plan_destroy, libgenphi), Cvoid, (Ptr{Cvoid},), plan[])
+        keep || destroy_plan(plan[])
     end
 end
 

@@ -36,12 +36,16 @@ def random_mating(n_ind, n_pro, n_gen, seed=SEED, skip_permille=0):
     """cfg3 / cfg4 shape: G discrete generations, last one = the n_pro probands.
 
     skip_permille > 0 draws a parent from generation g-2 instead of g-1 with that
-    probability (overlapping generations -> "dragged" individuals in the cuts).  The bench
-    shapes use 0: SURVEY.md 8(d) proposed 50, but that makes every deep ancestor reachable
-    at many parent-step distances and the cuts grow to 2e5 members (3.7 TB of algorithmic
-    traffic, two level matrices > 288 GB) instead of the ~3e4 / 260 GB the same section and
-    BASELINE.md size the configuration at; the dragged path is exercised by genea140,
-    geneaJi and small skip>0 pedigrees in the parity tests instead.
+    probability (overlapping generations -> "dragged" individuals in the cuts).  SURVEY.md
+    8(d) proposed 50 for both synthetic configurations.  At 1e6 individuals (cfg4) that makes
+    every deep ancestor reachable at many parent-step distances and the cuts grow to 2e5 members
+    (3.7 TB of algorithmic traffic, two level matrices > 288 GB) instead of the ~3e4 / 260 GB
+    the same section and BASELINE.md size the configuration at: the headline workload `cfg4`
+    uses 0, `cfg4o` 5, and the literal one is the column-panel case budgeted in DESIGN.md 6.2.
+    At 1e5 individuals (cfg3) the literal 50 fits one GPU and IS a bench workload and a
+    full-size oracle test (`cfg3s`: cuts to 20,540 members, most of them dragged along;
+    DESIGN.md 4.3c); `cfg3` is the same shape with 0.  Small skip > 0 pedigrees, genea140 and
+    geneaJi exercise the dragged path in the parity tests.
 
     Returns (ind, father, mother, sex, proband_ids); ids are 1..n_ind in generation order
     (parents always have smaller ids).  Sex alternates 1, 2 inside a generation.
