@@ -3350,6 +3350,40 @@ static int launch_wide_level(genphi_plan *p, int step, const float *psi, float *
     return GENPHI_OK;
 }
 
+// Zero-aware leading levels (sparse_levels.h): the first sweep of a plan that can use them builds the children lists of the eligible
+// steps and runs them once to count the non-zero entries of every cut; that fixes k, the last cut kept as row lists, for the life of the
+// plan (values do not depend on k; GENPHI_FLAG_NO_SPARSE runs the same plan densely).  The Float32 product sweep and the Float64-storage
+// sweep share the lists (integer values: exact for both).
+static int ensure_sparse_levels(genphi_plan *p, int kernel, PhaseTrace &trace)
+{
+    if (kernel != 0 || p->sparse_tried) return GENPHI_OK;
+    p->sparse_tried = true;
+    const Plan &pl = p->plan;
+    const int S = p->tun.sparse_k == -1 ? 0 : genphi::sparse_eligible_steps(pl);
+    if (S >= 2) {
+        std::vector<genphi::SparseStepDev> dev(S);
+        for (int s = 0; s < S; ++s)
+            dev[s] = genphi::SparseStepDev{p->dsteps[s].srcA, p->dsteps[s].srcB, p->dsteps[s].ord,
+                                           static_cast<int64_t>(pl.steps[s].work.size()) == pl.steps[s].n ? p->dsteps[s].work : nullptr};
+        genphi::SparseTuning stn;
+        stn.force_k = p->tun.sparse_k;
+        if (p->tun.sparse_permille > 0) stn.max_permille = p->tun.sparse_permille;
+        if (p->tun.sparse_min_cut >= 0) stn.min_cut = p->tun.sparse_min_cut;
+        if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
+        stn.classes = p->tun.sparse_classes;
+        std::string serr;
+        p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
+        if (p->sparse) {
+            const int rc = genphi::sparse_levels_calibrate(p->sparse, p->stream, serr);
+            if (rc) return fail(rc, "sparse levels: " + serr);
+        } else {
+            (void)hipGetLastError();          // (no memory for the row lists: the sweep stays dense)
+        }
+    }
+    trace.mark("sparse levels: lists + calibration");
+    return GENPHI_OK;
+}
+
 static int ensure_doubles(double **ptr, size_t *have, size_t need)
 {
     if (*have >= need && *ptr) return GENPHI_OK;
@@ -3361,7 +3395,7 @@ static int ensure_doubles(double **ptr, size_t *have, size_t need)
 
 // The whole sweep with Float64 level matrices (see level_naive64_kernel): rows [r0, r1) of the
 // proband matrix end up in p->result64 (row pitch = pitch of the last cut).
-static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genphi_stats *stats, bool timing)
+static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genphi_stats *stats, bool timing, bool no_sparse)
 {
     const Plan &pl = p->plan;
     const int L = pl.n_levels, n_steps = L - 1;
@@ -3397,16 +3431,36 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
         while (static_cast<int>(p->events.size()) < n_steps + 3) {
             hipEvent_t e; HIP_TRY(hipEventCreate(&e)); p->events.push_back(e);
         }
+    // the leading cuts as lists of their non-zero entries here too (integer values are exact for Float64 as for Float32, sparse_levels.h):
+    // the first dense matrix is written in Float64, compactly
+    {
+        PhaseTrace trace;
+        rc = ensure_sparse_levels(p, kernel, trace);
+        if (rc) return rc;
+    }
+    const int sparse_k = (kernel == 0 && p->sparse && !no_sparse) ? genphi::sparse_levels_k(p->sparse) : -1;
     const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
-    HIP_TRY(hipMemsetAsync(p->buf64[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(double), p->stream));
-    hipLaunchKernelGGL(half_identity64_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0, p->stream, p->buf64[0],
-                       static_cast<long long>(ld0), static_cast<int>(n0), static_cast<const int *>(nullptr), static_cast<int>(n0),
-                       static_cast<const int *>(nullptr));
-    HIP_TRY(hipGetLastError());
+    if (sparse_k < 0) {
+        HIP_TRY(hipMemsetAsync(p->buf64[0], 0, static_cast<size_t>((n0 + 1) * ld0) * sizeof(double), p->stream));
+        hipLaunchKernelGGL(half_identity64_kernel, dim3(static_cast<unsigned>((n0 + 255) / 256)), dim3(256), 0, p->stream, p->buf64[0],
+                           static_cast<long long>(ld0), static_cast<int>(n0), static_cast<const int *>(nullptr), static_cast<int>(n0),
+                           static_cast<const int *>(nullptr));
+        HIP_TRY(hipGetLastError());
+    }
     for (int s = 0; s < n_steps; ++s) {
         const LevelStep &st = pl.steps[s];
         const DeviceStep &d = p->dsteps[s];
+        if (s <= sparse_k) {
+            std::string serr;
+            rc = s < sparse_k ? genphi::sparse_levels_enqueue_step(p->sparse, s, p->stream, serr)
+                              : genphi::sparse_levels_enqueue_dense(p->sparse, p->buf64[(s + 1) & 1], true, true, st.ld, st.ld, p->stream, serr);
+            if (rc == GENPHI_OK && s == sparse_k) rc = genphi::sparse_levels_enqueue_flags(p->sparse, p->stream, serr);
+            if (rc) return fail(rc, "sparse levels: " + serr);
+            if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));
+            if (stats && s < GENPHI_MAX_STAT_LEVELS) stats->level_rows[s] = st.n;
+            continue;
+        }
         const double *psi = p->buf64[s & 1];
         const bool last = s == n_steps - 1;
         double *out = last ? p->result64 : p->buf64[(s + 1) & 1];
@@ -3453,6 +3507,8 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
     }
     (void)N;
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (sparse_k >= 0 && !genphi::sparse_levels_flags_ok(p->sparse))
+        return fail(GENPHI_ERR_DEVICE, "sparse levels: a row list did not have the length the plan recorded (internal error)");
     if (timing) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p->events[0], p->events[n_steps]));
@@ -3496,7 +3552,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     p->res_f64 = opts && (opts->flags & GENPHI_FLAG_STORAGE_F64);
     if (p->res_f64) {
         p->res_ld = pl.ld[L - 1];
-        return compute_f64(p, r0, r1, kernel, stats, timing);
+        return compute_f64(p, r0, r1, kernel, stats, timing, opts && (opts->flags & GENPHI_FLAG_NO_SPARSE));
     }
     if (p->popt.indices_only) return fail(GENPHI_ERR_ARG, "internal: an indices-only plan serves Float64-storage sweeps only");
     p->stay_active = kernel != 1;             // the per-entry kernel sweep (kernel = 1) knows no slots: every level is written compactly
@@ -3504,32 +3560,8 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     if (rc) return rc;
     trace.mark("ensure_level_buffers");
     const int n_steps = L - 1;
-    // Zero-aware leading levels (sparse_levels.h): the first product sweep of a plan builds the children lists of the eligible
-    // steps and runs them once to count the non-zero entries of every cut; that fixes k, the last cut kept as row lists, for
-    // the life of the plan (values do not depend on k; GENPHI_FLAG_NO_SPARSE runs the same plan densely).
-    if (kernel == 0 && !p->sparse_tried) {
-        p->sparse_tried = true;
-        const int S = p->tun.sparse_k == -1 ? 0 : genphi::sparse_eligible_steps(pl);
-        if (S >= 2) {
-            std::vector<genphi::SparseStepDev> dev(S);
-            for (int s = 0; s < S; ++s) dev[s] = genphi::SparseStepDev{p->dsteps[s].srcA, p->dsteps[s].srcB, p->dsteps[s].ord, p->dsteps[s].work};
-            genphi::SparseTuning stn;
-            stn.force_k = p->tun.sparse_k;
-            if (p->tun.sparse_permille > 0) stn.max_permille = p->tun.sparse_permille;
-            if (p->tun.sparse_min_cut >= 0) stn.min_cut = p->tun.sparse_min_cut;
-            if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
-            stn.classes = p->tun.sparse_classes;
-            std::string serr;
-            p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
-            if (p->sparse) {
-                rc = genphi::sparse_levels_calibrate(p->sparse, p->stream, serr);
-                if (rc) return fail(rc, "sparse levels: " + serr);
-            } else {
-                (void)hipGetLastError();          // (no memory for the row lists: the sweep stays dense)
-            }
-        }
-        trace.mark("sparse levels: lists + calibration");
-    }
+    rc = ensure_sparse_levels(p, kernel, trace);
+    if (rc) return rc;
     const int sparse_k = (kernel == 0 && p->sparse && !(opts && (opts->flags & GENPHI_FLAG_NO_SPARSE))) ? genphi::sparse_levels_k(p->sparse) : -1;
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
@@ -3712,7 +3744,7 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
                     // cuts 0..sparse_k are row lists: a list step, or (s == sparse_k) the step that writes cut s+1 as a dense matrix
                     std::string serr;
                     rc = s < sparse_k ? genphi::sparse_levels_enqueue_step(p->sparse, s, p->stream, serr)
-                                      : genphi::sparse_levels_enqueue_dense(p->sparse, p->buf[bid[s + 1]], st.ld, st.width, p->stream, serr);
+                                      : genphi::sparse_levels_enqueue_dense(p->sparse, p->buf[bid[s + 1]], false, false, st.ld, st.width, p->stream, serr);
                     if (rc == GENPHI_OK && s == sparse_k) rc = genphi::sparse_levels_enqueue_flags(p->sparse, p->stream, serr);
                     if (rc) return fail(rc, "sparse levels: " + serr);
                     if (timing) HIP_TRY(hipEventRecord(p->events[s + 1], p->stream));

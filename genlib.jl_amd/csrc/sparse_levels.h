@@ -66,8 +66,10 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
 int sparse_levels_k(const SparseLevels *sl);                  // last sparse cut, or -1
 // step s of the sweep: s < k enqueues the row-list step (s == 0 also the lists of 1/2 I and the counters' reset) ...
 int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std::string &err);
-// ... s == k the step that writes cut k+1 as a dense matrix: out = (n + 1) rows of pitch ld, columns [0, width) written
-int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long long width, hipStream_t stream, std::string &err);
+// ... s == k the step that writes cut k+1 as a dense matrix: out = (n + 1) rows of pitch ld, columns [0, width) written; Float32 or
+// (f64) Float64 entries; compact: rows and columns in the cut's storage order whatever the plan says about slots (the Float64 sweep)
+int sparse_levels_enqueue_dense(SparseLevels *sl, void *out, bool f64, bool compact, long long ld, long long width, hipStream_t stream,
+                                std::string &err);
 // ... and after the last sparse step of a sweep: the error flags of the row-list steps are copied to the host (asynchronously); once the
 // stream is synchronised sparse_levels_flags_ok says whether every row had the length the plan recorded for it
 int sparse_levels_enqueue_flags(SparseLevels *sl, hipStream_t stream, std::string &err);

@@ -71,7 +71,7 @@ struct SpArgs {
     unsigned *stat;               // [0] entries of Y written so far (calibration run), [2] 1 = a row or the arena overflowed, 2 = a row's length
                                   // differs from the plan's
     // sparse -> dense step
-    float *out;
+    void *out;                    // Float32 matrix (gen.phi) or Float64 (the Float64-storage sweep)
     long long ld;
     int width, chunk_cols, n_chunks;
     float unit_out;               // 2^-(2s+3): one integer unit of cut s+1
@@ -313,12 +313,30 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     if (a.fixed && run != place.y && tid == 0) atomicOr(&a.stat[2], 2u);
 }
 
+// four consecutive entries of the dense matrix from their integer values (exact conversions), as non-temporal 16-byte stores; Float64
+// for the Float64-storage sweep (gen.f, pairwise phi: src/compute.jl:66-95 works in Float64 throughout)
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store4(float *dst, unsigned x, unsigned y, unsigned z, unsigned w, float unit)
+{
+    const f4_t v = {static_cast<float>(x) * unit, static_cast<float>(y) * unit, static_cast<float>(z) * unit, static_cast<float>(w) * unit};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(dst));
+}
+__device__ __forceinline__ void store4(double *dst, unsigned x, unsigned y, unsigned z, unsigned w, float unit)
+{
+    const double u = static_cast<double>(unit);
+    const d2v_t a = {static_cast<double>(x) * u, static_cast<double>(y) * u}, b = {static_cast<double>(z) * u, static_cast<double>(w) * u};
+    __builtin_nontemporal_store(a, reinterpret_cast<d2v_t *>(dst));
+    __builtin_nontemporal_store(b, reinterpret_cast<d2v_t *>(dst + 2));
+}
+
 // ---- rows of Y_k -> the dense matrix of cut k+1: one workgroup per (row, chunk of columns) -------------------------------
 // The chunk's entries are accumulated in LDS (integer units) and leave as whole 16-byte stores, zeros included: the step
 // writes what a FULL / SPLIT row kernel writes (columns [0, width) of every row, the all-zero row n) and reads only lists.
+template <typename OutT>
 __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
 {
     extern __shared__ unsigned acc[];
+    OutT *const outm = static_cast<OutT *>(a.out);
     const int tid = threadIdx.x;
     // Workgroups b, b + 8, b + 16 ... run on the same XCD: the chunks of one row go there back to back, and so do the rows that follow
     // it in the planner's work order (siblings adjacent, families chained along shared mothers) -- the lists of a row's sources are then
@@ -330,9 +348,8 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     const int c0 = chunk * a.chunk_cols;
     if (i >= a.n) {                                        // the "none" row: zeros over the whole pitch
         const int c1 = static_cast<int>(min(static_cast<long long>(c0) + a.chunk_cols, a.ld));
-        float *orow = a.out + static_cast<long long>(a.zrow) * a.ld;
-        const f4_t z = {0.f, 0.f, 0.f, 0.f};
-        for (int j = c0 + 4 * tid; j < c1; j += 1024) __builtin_nontemporal_store(z, reinterpret_cast<f4_t *>(orow + j));
+        OutT *orow = outm + static_cast<long long>(a.zrow) * a.ld;
+        for (int j = c0 + 4 * tid; j < c1; j += 1024) store4(orow + j, 0u, 0u, 0u, 0u, a.unit_out);
         return;
     }
     const int c1 = min(c0 + a.chunk_cols, a.width);
@@ -358,12 +375,10 @@ __global__ void __launch_bounds__(256) sparse_dense_kernel(const SpArgs a)
     __syncthreads();
     if (diag_here && tid == 0) acc[si - c0] = a.half_out + 2u * fm_i;
     __syncthreads();
-    float *orow = a.out + static_cast<long long>(si) * a.ld + c0;
+    OutT *orow = outm + static_cast<long long>(si) * a.ld + c0;
     for (int j = 4 * tid; j < c1 - c0; j += 1024) {
         const uint4 u = *reinterpret_cast<const uint4 *>(acc + j);
-        const f4_t v = {static_cast<float>(u.x) * a.unit_out, static_cast<float>(u.y) * a.unit_out, static_cast<float>(u.z) * a.unit_out,
-                        static_cast<float>(u.w) * a.unit_out};
-        __builtin_nontemporal_store(v, reinterpret_cast<f4_t *>(orow + j));
+        store4(orow + j, u.x, u.y, u.z, u.w, a.unit_out);
     }
 }
 
@@ -753,7 +768,7 @@ int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std:
     return rc;
 }
 
-int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long long width, hipStream_t stream, std::string &err)
+int sparse_levels_enqueue_dense(SparseLevels *sl, void *out, bool f64, bool compact, long long ld, long long width, hipStream_t stream, std::string &err)
 {
     if (!sl || sl->k < 1) { err = "sparse_levels_enqueue_dense: no sparse cut"; return GENPHI_ERR_ARG; }
     SpArgs a = args_for(sl, sl->k);
@@ -765,9 +780,12 @@ int sparse_levels_enqueue_dense(SparseLevels *sl, float *out, long long ld, long
     a.n_chunks = static_cast<int>((std::max(ld, width) + a.chunk_cols - 1) / a.chunk_cols);
     const size_t lds = static_cast<size_t>(a.chunk_cols) * sizeof(unsigned);
     a.rows = sl->dev[sl->k].work;
-    a.slot = sl->slot[sl->k];
-    a.zrow = sl->zrow[sl->k];
-    hipLaunchKernelGGL(sparse_dense_kernel, dim3(static_cast<unsigned>((a.n + 1 + 7) / 8 * 8) * a.n_chunks), dim3(256), lds, stream, a);
+    // (the Float64 sweep and the per-entry sweep store every cut compactly: no slots, the "none" row at n)
+    a.slot = compact ? nullptr : sl->slot[sl->k];
+    a.zrow = compact ? a.n : sl->zrow[sl->k];
+    const dim3 grid(static_cast<unsigned>((a.n + 1 + 7) / 8 * 8) * a.n_chunks);
+    if (f64) hipLaunchKernelGGL(sparse_dense_kernel<double>, grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(sparse_dense_kernel<float>, grid, dim3(256), lds, stream, a);
     SP_TRY(hipGetLastError());
     return GENPHI_OK;
 }

@@ -1544,6 +1544,16 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
     for _ in range(3):                                              # graph replay (17 steps)
         pl.compute_device()
     _assert_equal(pl.result_to_host(), gold)
+    # the Float64-storage sweep (gen.f, pairwise phi) runs its leading cuts on the same lists and writes its first dense matrix in Float64
+    pl.compute_device(storage64=True)
+    f64_sparse = pl.result_to_host_f64()
+    pl.compute_device(storage64=True, no_sparse=True)
+    f64_dense = pl.result_to_host_f64()
+    assert np.array_equal(f64_sparse, f64_dense) and np.abs(f64_sparse - gold.astype(np.float64)).max() < 1e-7
+    oped = oracle.Pedigree.from_file(gen.genea140)
+    pro140 = gen.pro(ped)
+    for a_, b_ in ((0, 1), (3, 77), (139, 139), (20, 5)):
+        assert f64_sparse[a_, b_] == oped.phi_pair(int(pro140[a_]), int(pro140[b_]))      # the exact Float64 recursion, src/compute.jl:66-95
     pl.close()
     for force in ("1", "4", "9", "11", "-1"):
         monkeypatch.setenv("GENPHI_SPARSE_K", force)
