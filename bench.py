@@ -176,14 +176,14 @@ def level_bytes(pl, sizes, both, esz=4.0, product_sweep=True, sparse=True):
     alg = [esz * (a * a + b * b) for a, b in zip(sizes[:-1], sizes[1:])]
     in_place = [bool(pl.step_slots(k)[0] & 1) for k in range(len(alg))]
     moved = [x - (esz * 2.0 * both[k] * both[k] if in_place[k] and product_sweep else 0.0) for k, x in enumerate(alg)]
-    k_sp = pl.sparse_levels()[0] if (product_sweep and sparse) else -1
+    k_sp = pl.sparse_levels()[0] if sparse else -1         # (the Float32 product sweep and the Float64-storage sweep run them)
     if k_sp >= 1:
         ent = pl.sparse_entries()
         for k in range(k_sp + 1):
             if k < k_sp:
                 moved[k] = 8.0 * (2.0 * ent[k] + ent[k + 1])
             else:
-                moved[k] = 8.0 * 2.0 * ent[k] + 4.0 * sizes[k + 1] * sizes[k + 1]
+                moved[k] = 8.0 * 2.0 * ent[k] + esz * sizes[k + 1] * sizes[k + 1]
     return alg, moved, in_place
 
 
@@ -606,7 +606,7 @@ def main():
         if f64:                                            # row-staged Float64 kernel up to 10,239-wide cuts, per-entry kernel beyond
             names = {m: "level_full64_kernel / level_naive64_kernel" for m in (0, 1, 2)}
         by_kernel = {}
-        sp = sparse_summary(pl, sizes) if (not f64 and args.kernel == 0 and not args.no_sparse) else {"last_sparse_cut": -1, "nonzero_frac": []}
+        sp = sparse_summary(pl, sizes) if (args.kernel == 0 and not args.no_sparse) else {"last_sparse_cut": -1, "nonzero_frac": []}
         for k, t in enumerate(lvl_kernel):
             small = k < len(lvl_kernel) - 1 and sizes[k] <= 128 and sizes[k + 1] <= 128 and args.kernel == 0
             nm = "level_naive_kernel" if args.kernel == 1 else ("levels_small_kernel" if small else names.get(modes[k], "?"))
@@ -618,7 +618,7 @@ def main():
         # the algorithmic bytes 4 (n_k^2 + n_{k+1}^2) count it twice (read + write), so `frac` on them is no bandwidth figure and
         # can exceed 1.  For such steps `frac` / `achieved` use the bytes the formulation still has to move, 4 (n_k^2 + n_{k+1}^2)
         # - 8 n_dragged^2; the purely algorithmic figure stays under `algorithmic_frac`.  No in-place step: the two coincide.
-        _, byt_moved, in_place = level_bytes(pl, sizes, both, esz, product_sweep=not f64 and args.kernel == 0, sparse=not args.no_sparse)
+        _, byt_moved, in_place = level_bytes(pl, sizes, both, esz, product_sweep=not f64 and args.kernel == 0, sparse=args.kernel == 0 and not args.no_sparse)
         share = [(min(r, b) / b if b else 1.0) for r, b in zip(level_rows, sizes[1:])] if level_rows is not None else [1.0] * len(byt)
         byt_alg = list(byt)
         byt = [x * f for x, f in zip(byt_moved, share)]
@@ -628,7 +628,7 @@ def main():
         # `frac`: on the algorithmic bytes (the bench contract; an implementation that elides traffic shows as algorithmic > measured,
         # SURVEY.md 8(d)) -- unless that is no bandwidth figure at all: steps that stay in place, or a sweep whose bytes are mostly zeros
         # that never move (genea140: 1.5 x the peak), then on the bytes still to be moved.  Both are always on the line.
-        on_alg = achieved_alg <= HBM_PEAK_GBS and not any(in_place)
+        on_alg = achieved_alg <= HBM_PEAK_GBS and not (any(in_place) and not f64 and args.kernel == 0)
         achieved = achieved_alg if on_alg else achieved_moved
         tot_b = float(sum(byt_alg)) if on_alg else float(sum(byt))
         moved_total = pl.algorithmic_bytes * esz / 4.0 - (float(sum(byt_alg)) - float(sum(byt)))      # whole sweep: what still moves
