@@ -572,9 +572,11 @@ def main():
     # N > 1: every rank copies ITS row block to its host (the 40 GB copy of cfg4 split N ways: the end-to-end win of the row shards)
     shard_d2h_ms = None
     if world > 1 and not args.no_d2h and not f64:
+        import psutil
         t_own = 0.0
-        if not empty_shard:
-            barrier()
+        fits_host = psutil.virtual_memory().available > (r1 - r0) * n * 4 * world + (16 << 30)      # (all ranks of the node copy at once)
+        barrier()                                          # (every rank, also one without rows: it is a collective)
+        if not empty_shard and fits_host:
             t0d = time.perf_counter()
             host = pl.result_to_host()
             t_own = (time.perf_counter() - t0d) * 1e3

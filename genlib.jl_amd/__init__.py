@@ -270,12 +270,17 @@ def f(pedigree, IDs, device=None):
     if not np.any(both):
         return out
     parents = np.unique(np.concatenate([fa[both], mo[both]]))     # sorted, like a proband list
-    pl = plan(pedigree, parents)
+    pl, key = _plan_for(pedigree, parents, device)                # (kept per pedigree like gen.phi's plans: f over the same IDs again pays the sweep)
+    keep = False
     try:
         pl.compute_device(device=device, storage64=True)
         out[both] = pl.result_entries(np.searchsorted(parents, fa[both]), np.searchsorted(parents, mo[both])).astype(np.float32)
+        keep = key is not None and _keep_plan(pedigree, key, pl, parents)
     finally:
-        pl.close()
+        if not keep:
+            if key is not None and key in pedigree._plans and pedigree._plans[key][0] is pl:
+                del pedigree._plans[key]
+            pl.close()
     return out
 
 

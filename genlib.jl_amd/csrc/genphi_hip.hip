@@ -3595,6 +3595,21 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
         HIP_TRY(genphi::cached_malloc(reinterpret_cast<void **>(&p->d_shard_out_rows), n_rows * sizeof(int)));
         p->shard_cap = n_rows; p->shard_r0 = p->shard_r1 = -1;
     }
+    // The whole result by a row-kernel last step in proband order: the step's own work order and walk lists (built by the planner and the
+    // upload for exactly these rows) ARE the shard's -- no second reuse order, hub walk and upload (7 ms of a first call at 1e5 probands)
+    const bool whole_by_rows = r0 == 0 && r1 == pl.n_pro && !need_perm && n_steps > 0 && pl.steps[n_steps - 1].mode != genphi::kModeWide &&
+                               static_cast<int64_t>(pl.steps[n_steps - 1].work.size()) == n_rows &&
+                               (pl.steps[n_steps - 1].mode != genphi::kModeSplit || p->dsteps[n_steps - 1].groups.desc != nullptr);
+    if ((p->shard_r0 != r0 || p->shard_r1 != r1) && whole_by_rows) {
+        drop_graph(p);
+        const int *work = p->dsteps[n_steps - 1].work;
+        HIP_TRY(hipMemcpyAsync(p->d_shard_rows, work, n_rows * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_shard_out_rows, work, n_rows * sizeof(int), hipMemcpyDeviceToDevice, p->stream));      // (output row = storage row)
+        p->shard_groups = p->dsteps[n_steps - 1].groups;
+        (void)genphi::cached_free(p->sh_blob); p->sh_blob = nullptr; p->sh_valid = false;
+        p->sh_steps.assign(std::max(n_steps, 1), genphi_plan::ShardStep());
+        p->shard_r0 = r0; p->shard_r1 = r1;
+    }
     if (p->shard_r0 != r0 || p->shard_r1 != r1) {
         drop_graph(p);                               // shard lists and sh_blob are rewritten / reallocated below
         // work order of the shard: the planner's reuse order (sibling groups, chained along
