@@ -27,7 +27,10 @@ if [ "$PART" = bench ] || [ "$PART" = all ]; then
   done
   for w in cfg2all cfg2q; do python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$O/${TAG}_bench_$w.json" 2> "$O/bench_$w.err"; echo "bench $w"; done
   python bench.py --workload cfg4o --steps 5 --warmup 1 --no-cpu-baseline > "$O/${TAG}_bench_cfg4o.json" 2> "$O/bench_cfg4o.err"; echo "bench cfg4o"
-  for w in cfg3 cfg2; do python bench.py --workload $w --storage f64 --steps 10 --warmup 2 > "$O/${TAG}_bench_${w}_f64.json" 2> "$O/bench_${w}_f64.err"; done
+  for w in cfg3 cfg2; do
+    python bench.py --workload $w --storage f64 --steps 10 --warmup 2 > "$O/${TAG}_bench_${w}_f64.json" 2> "$O/bench_${w}_f64.err"
+    python bench.py --workload $w --storage f64 --steps 10 --warmup 2 --no-sparse > "$O/${TAG}_bench_${w}_f64_every_level_dense.json" 2>/dev/null
+  done
   for w in sparse140 sparse2k; do python bench.py --workload $w --steps 5 --warmup 1 > "$O/${TAG}_bench_$w.json" 2> "$O/bench_$w.err"; done
   python bench.py --workload cfg3 --exchange --steps 20 --warmup 3 > "$O/${TAG}_bench_panel_cfg3_w1.json" 2> "$O/panel_w1.err"
   GENPHI_PLAN_CACHE=0 python profiles/microbench/call_wall.py cfg2 cfg3 cfg3s cfg5 > "$O/${TAG}_call_wall_one_shot.out" 2>&1
