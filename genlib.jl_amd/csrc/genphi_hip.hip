@@ -2018,6 +2018,7 @@ struct Tuning {
     int sparse_permille = -1;      // GENPHI_SPARSE_PERMILLE  tuning: a cut stays sparse while at most this share (1/1000) of its entries is non-zero
     int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
     int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
+    int sparse_batch = 0;          // GENPHI_SPARSE_BATCH     A/B: list entries in flight per thread of a long row's workgroup, 4 or 8 (default 4; 8 measured slower)
     int d2h_chunk_mb = 0;          // GENPHI_D2H_CHUNK_MB     tuning: size of a pinned staging chunk of genphi_result_to_host (default 16, 4 for results below 2 GB)
     int sparse_classes = -1;       // GENPHI_SPARSE_CLASSES   A/B + test: 1 / 0 = a row-list step is always / never one launch per class of row lengths (default: where lengths differ much)
 };
@@ -2035,7 +2036,7 @@ static const char *const kTuningNames[] = {
     "GENPHI_STAY_FAMILY", "GENPHI_MAX_GROUP", "GENPHI_MAX_RUN", "GENPHI_FULL_BS", "GENPHI_NO_IDENTITY", "GENPHI_CERT_MIN_EXP", "GENPHI_DBG_STEP",
     "GENPHI_NO_FAST", "GENPHI_MAX_CPT", "GENPHI_FAST_NT", "GENPHI_WIDE_ROUTE", "GENPHI_TT_NOALIGN", "GENPHI_NO_SHARD_PRUNE", "GENPHI_SHARD_FORCE",
     "GENPHI_SHARD_PRUNE_MIN_STEP", "GENPHI_NO_SMALL", "GENPHI_NO_GRAPH", "GENPHI_D2H_THREADS", "GENPHI_D2H_PAGEABLE", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE",
-    "GENPHI_D2H_CHUNK_MB", "GENPHI_TEST_FAIL_ALLOC", "GENPHI_SPARSE_K", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_CLASSES"};
+    "GENPHI_D2H_CHUNK_MB", "GENPHI_TEST_FAIL_ALLOC", "GENPHI_SPARSE_K", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_BATCH"};
 
 // the settings of a plan: from a genphi_tuning when one is given, else from the environment -- which the library reads only under
 // GENPHI_ENV_HOOKS=1 (planner.h: env_hook)
@@ -2103,6 +2104,7 @@ static Tuning tuning_from(const genphi_tuning *tu)
     t.sparse_chunk = geti("GENPHI_SPARSE_CHUNK", 0);
     t.sparse_classes = geti("GENPHI_SPARSE_CLASSES", -1);
     t.d2h_chunk_mb = geti("GENPHI_D2H_CHUNK_MB", 0);
+    t.sparse_batch = geti("GENPHI_SPARSE_BATCH", 0);
     return t;
 }
 
@@ -3371,6 +3373,7 @@ static int ensure_sparse_levels(genphi_plan *p, int kernel, PhaseTrace &trace)
         if (p->tun.sparse_min_cut >= 0) stn.min_cut = p->tun.sparse_min_cut;
         if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
         stn.classes = p->tun.sparse_classes;
+        if (p->tun.sparse_batch == 4 || p->tun.sparse_batch == 8) stn.long_batch = p->tun.sparse_batch;
         std::string serr;
         p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
         if (p->sparse) {

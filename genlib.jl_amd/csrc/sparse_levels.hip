@@ -189,7 +189,7 @@ __device__ __forceinline__ int block_scan(int v, int tid, int *wsum, int &total)
 // (ascending) row and the row its length; pass 2 adds the contributions into the row's values in LDS (ds_add_u32); the
 // diagonal of a new member is set from fm; then the row is used where it stands: the kinships its children's diagonals
 // need are looked up (fm_out), and it leaves expanded to the columns of the next cut (a row of Y_{s+1}).
-template <int NT>
+template <int NT, int KB>
 __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
 {
     extern __shared__ unsigned lds_u[];
@@ -206,7 +206,9 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
     const SrcRows r = src_rows(a, A, B);
-    EntryCache<NT> ec;
+    // (KB entries per thread in flight and in registers between the passes: four; eight for the four-wavefront rows was measured slower,
+    // sparse_levels.h)
+    EntryCache<NT, KB> ec;
     load_first(a, r, tid, ec);
     const uint2 place = a.fixed ? a.rowd_out[i] : make_uint2(0u, 0u);
     const unsigned fm_i = (new_i && A != none && B != none) ? a.fm_in[i] : 0u;
@@ -265,12 +267,12 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     // order of a row's entries in Y is free.
     auto expand = [&](bool store, unsigned off, unsigned limit) -> unsigned {
         unsigned run = 0u;
-        for (int t0 = 0; t0 < total; t0 += kBatch * NT) {
-            int k0[kBatch], k1[kBatch];
-            unsigned v[kBatch];
+        for (int t0 = 0; t0 < total; t0 += KB * NT) {
+            int k0[KB], k1[KB];
+            unsigned v[KB];
             int mine = 0;
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
+            for (int b = 0; b < KB; ++b) {
                 const int t = t0 + b * NT + tid;
                 const bool ok = t < total;
                 const int q = ok ? cols[t] : 0;
@@ -279,12 +281,12 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
                 k1[b] = ok ? a.chn_off[q + 1] : k0[b];
             }
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) mine += k1[b] - k0[b];
+            for (int b = 0; b < KB; ++b) mine += k1[b] - k0[b];
             int it_total;
             unsigned at = run + static_cast<unsigned>(block_scan<NT>(mine, tid, wsum, it_total));
             if (store) {
 #pragma unroll
-                for (int b = 0; b < kBatch; ++b)
+                for (int b = 0; b < KB; ++b)
                     for (int k = k0[b]; k < k1[b]; ++k, ++at) {
                         const unsigned cw = a.chn[k];
                         if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v[b] * ((cw >> 31) + 1u));
@@ -629,8 +631,9 @@ static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int
     a.cap = cap;
     a.wp = wp_for(a.n, wide ? 256 : 64);
     const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
-    if (wide) hipLaunchKernelGGL(sparse_step_kernel<256>, dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(sparse_step_kernel<64>, dim3(static_cast<unsigned>(n_rows)), dim3(64), lds, stream, a);
+    if (wide && sl->tun.long_batch >= 8) hipLaunchKernelGGL((sparse_step_kernel<256, 8>), dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
+    else if (wide) hipLaunchKernelGGL((sparse_step_kernel<256, kBatch>), dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((sparse_step_kernel<64, kBatch>), dim3(static_cast<unsigned>(n_rows)), dim3(64), lds, stream, a);
     SP_TRY(hipGetLastError());
     return GENPHI_OK;
 }
