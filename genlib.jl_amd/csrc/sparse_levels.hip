@@ -55,8 +55,10 @@ struct SpArgs {
     unsigned half_out;            // 1/2 in units of cut s+1: 2^(2s+2)
     // row-list step: cut s+1 written as rows of Y_{s+1} (columns = members of cut s+2)
     uint2 *ent_out;
-    uint2 *rowd_out;              // written by the calibration run, read by every later sweep (fixed != 0)
-    int fixed;
+    uint2 *rowd_out;              // (place, length) of every row: lengths by the calibration run's counting launch, places by its scan;
+    int count_only;               //   read by every other launch.  count_only != 0: the counting launch (no values, no lists written)
+    const unsigned *stop;         // (calibration run) != nullptr: a word that names the first cut NOT to compute once a cut proved too dense (0: none
+    unsigned level;               //   yet) -- launches for that cut and the ones behind it end at once; level = the cut this launch writes
     unsigned ent_cap;             // entries the arena written holds
     const int *chn_off;           // children of member q of cut s+1 in cut s+2: chn[chn_off[q] .. chn_off[q + 1])
     const unsigned *chn;          //   position in cut s+2 | 0x80000000 when the child is q itself (dragged: weight 1)
@@ -197,9 +199,12 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     unsigned *vals = bm + a.wp;
     unsigned short *pre = reinterpret_cast<unsigned short *>(vals + a.cap);
     unsigned short *cols = pre + a.wp;
-    __shared__ unsigned off_slot;
     __shared__ int wsum[NT / 64 + 1];
     const int tid = threadIdx.x;
+    if (a.stop) {                                          // (workgroup-uniform)
+        const unsigned first_skipped = *a.stop;
+        if (first_skipped != 0u && a.level >= first_skipped) return;
+    }
     const int w = a.remap ? xcd_remap(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x);
     const int i = a.rows ? a.rows[w] : w;
     const int A = a.srcA[i], B = a.srcB[i];
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     // sparse_levels.h)
     EntryCache<NT, KB> ec;
     load_first(a, r, tid, ec);
-    const uint2 place = a.fixed ? a.rowd_out[i] : make_uint2(0u, 0u);
+    const uint2 place = a.count_only ? make_uint2(0u, 0u) : a.rowd_out[i];
     const unsigned fm_i = (new_i && A != none && B != none) ? a.fm_in[i] : 0u;
     const int mt0 = a.mt_off[i], mt1 = a.mt_off[i + 1];
     for (int w = tid; w < a.wp; w += NT) bm[w] = 0u;
@@ -225,11 +230,30 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     for (int w = w0; w < w0 + T; ++w) cnt += __popc(bm[w]);
     int total;
     int pos = block_scan<NT>(cnt, tid, wsum, total);
-    if (total > a.cap) {                                   // (workgroup-uniform) the row does not fit: the cut is too dense to stay sparse
-        if (tid == 0) {
-            atomicOr(&a.stat[2], 1u);
-            if (!a.fixed) { a.rowd_out[i] = make_uint2(0u, 0u); a.rnz_out[i] = 0u; }
+    if (a.count_only) {
+        // the counting launch of a calibration run: the row's non-zero entries and the length of its row of Y_{s+1} (every column's
+        // children), straight from the bitmap -- no column list, so a row of any length is counted
+        int len = 0;
+        for (int w = w0; w < w0 + T; ++w) {
+            unsigned bits = bm[w];
+            while (bits) {
+                const int q = w * 32 + __ffs(bits) - 1;
+                len += a.chn_off[q + 1] - a.chn_off[q];
+                bits &= bits - 1u;
+            }
         }
+        int ltot;
+        (void)block_scan<NT>(len, tid, wsum, ltot);
+        if (tid == 0) {
+            const bool fits = total <= a.cap;              // (the launch that writes the row holds it in LDS: longer rows void the cut)
+            a.rowd_out[i] = make_uint2(0u, fits ? static_cast<unsigned>(ltot) : 0u);
+            a.rnz_out[i] = static_cast<unsigned>(total);
+            if (!fits) atomicOr(&a.stat[2], 1u);
+        }
+        return;
+    }
+    if (total > a.cap) {                                   // (workgroup-uniform) the row does not fit: the cut is too dense to stay sparse
+        if (tid == 0) atomicOr(&a.stat[2], 1u);
         return;
     }
     for (int w = w0; w < w0 + T; ++w) {
@@ -265,7 +289,7 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     // the row leaves as a row of Y_{s+1}: every entry (q, v) goes to the children of q.  kBatch entries per thread at a time, their
     // children ranges loaded together (entry -> range -> children are dependent round trips through L2), one scan per batch; the
     // order of a row's entries in Y is free.
-    auto expand = [&](bool store, unsigned off, unsigned limit) -> unsigned {
+    auto expand = [&](unsigned off, unsigned limit) -> unsigned {
         unsigned run = 0u;
         for (int t0 = 0; t0 < total; t0 += KB * NT) {
             int k0[KB], k1[KB];
@@ -284,35 +308,58 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
             for (int b = 0; b < KB; ++b) mine += k1[b] - k0[b];
             int it_total;
             unsigned at = run + static_cast<unsigned>(block_scan<NT>(mine, tid, wsum, it_total));
-            if (store) {
 #pragma unroll
-                for (int b = 0; b < KB; ++b)
-                    for (int k = k0[b]; k < k1[b]; ++k, ++at) {
-                        const unsigned cw = a.chn[k];
-                        if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v[b] * ((cw >> 31) + 1u));
-                    }
-            }
+            for (int b = 0; b < KB; ++b)
+                for (int k = k0[b]; k < k1[b]; ++k, ++at) {
+                    const unsigned cw = a.chn[k];
+                    if (at < limit) a.ent_out[off + at] = make_uint2(cw & 0x7fffffffu, v[b] * ((cw >> 31) + 1u));
+                }
             run += static_cast<unsigned>(it_total);
         }
         return run;
     };
-    unsigned off = place.x;
-    if (!a.fixed) {                                        // calibration run: the row's length first, then its place
-        const unsigned ltot = expand(false, 0u, 0u);
-        if (tid == 0) off_slot = atomicAdd(&a.stat[0], ltot);
-        __syncthreads();
-        off = off_slot;
-        if (off + ltot > a.ent_cap || off + ltot < off) {
-            if (tid == 0) { atomicOr(&a.stat[2], 1u); a.rowd_out[i] = make_uint2(0u, 0u); a.rnz_out[i] = 0u; }
-            return;
-        }
-        if (tid == 0) {                                    // (the host takes the longest row and the number of non-zero entries from rnz)
-            a.rowd_out[i] = make_uint2(off, ltot);
-            a.rnz_out[i] = static_cast<unsigned>(total);
-        }
+    const unsigned run = expand(place.x, place.y);
+    if (run != place.y && tid == 0) atomicOr(&a.stat[2], 2u);
+}
+
+// places of the rows of a cut from their lengths (calibration run): rowd[i].x = sum of rowd[j].y over j < i; the total goes to stat[0];
+// a cut whose lists do not fit the arena is voided (every length 0, overflow flag).  One workgroup: a cut has < 65,535 rows.
+__global__ void __launch_bounds__(1024) sparse_place_kernel(uint2 *rowd, int n, unsigned ent_cap, unsigned long long stop_entries, unsigned *stat,
+                                                            unsigned *stop, unsigned level)
+{
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    if (*stop != 0u && level >= *stop) {                   // (a cut before this one was too dense: this one does not exist)
+        if (tid == 0) atomicOr(&stat[2], 4u);
+        return;
     }
-    const unsigned run = expand(true, off, a.fixed ? place.y : 0xffffffffu);
-    if (a.fixed && run != place.y && tid == 0) atomicOr(&a.stat[2], 2u);
+    const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
+    unsigned long long sum = 0;
+    for (int i = i0; i < i1; ++i) sum += rowd[i].y;
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the 1024 partial sums
+        const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long total = part[1023];
+    const bool ok = total <= static_cast<unsigned long long>(ent_cap);
+    unsigned long long off = part[tid] - sum;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned len = rowd[i].y;
+        rowd[i] = ok ? make_uint2(static_cast<unsigned>(off), len) : make_uint2(0u, 0u);
+        off += len;
+    }
+    if (tid == 0) {
+        stat[0] = ok ? static_cast<unsigned>(total) : 0u;
+        if (!ok) atomicOr(&stat[2], 1u);
+        // a void cut ends the run here; one too dense to be worth a list step behind it (its lists alone are a quarter of a dense level's
+        // bytes) is still written -- it may be the last sparse one -- and ends the run behind it
+        if (!ok || stat[2] != 0u) *stop = level;
+        else if (total > stop_entries) *stop = level + 1u;
+    }
 }
 
 // four consecutive entries of the dense matrix from their integer values (exact conversions), as non-temporal 16-byte stores; Float64
@@ -605,7 +652,7 @@ static SpArgs args_for(const SparseLevels *sl, int s)
         a.fm_out = sl->fm[s + 1];
         a.rnz_out = sl->rnz[s + 1];
     }
-    a.fixed = sl->calibrated ? 1 : 0;
+    a.count_only = 0;
     a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu));
     return a;
 }
@@ -622,15 +669,20 @@ static int launch_identity(SparseLevels *sl, hipStream_t stream, std::string &er
 
 // one launch of the row-list step: n_rows members (rows == nullptr: all of them, in order), `cap` entries per row in LDS, four
 // wavefronts per row when `wide`
-static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int cap, bool wide, hipStream_t stream, std::string &err)
+static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int cap, bool wide, hipStream_t stream, std::string &err,
+                       bool count_only = false, bool calibrating = false)
 {
     if (n_rows <= 0) return GENPHI_OK;
     SpArgs a = args_for(sl, s);
+    a.count_only = count_only ? 1 : 0;
+    a.stop = calibrating ? sl->stat + 3 : nullptr;         // (word 3 of cut 0's counters, cleared by sparse_identity_kernel)
+    a.level = static_cast<unsigned>(s + 1);
     a.rows = rows;
     a.remap = (rows != nullptr && rows == sl->dev[s].work) ? 1 : 0;
     a.cap = cap;
     a.wp = wp_for(a.n, wide ? 256 : 64);
-    const size_t lds = 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
+    // (the counting launch keeps only the bitmap in LDS)
+    const size_t lds = count_only ? 4 * static_cast<size_t>(a.wp) : 6 * (static_cast<size_t>(a.wp) + static_cast<size_t>(a.cap));
     if (wide && sl->tun.long_batch >= 8) hipLaunchKernelGGL((sparse_step_kernel<256, 8>), dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
     else if (wide) hipLaunchKernelGGL((sparse_step_kernel<256, kBatch>), dim3(static_cast<unsigned>(n_rows)), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((sparse_step_kernel<64, kBatch>), dim3(static_cast<unsigned>(n_rows)), dim3(64), lds, stream, a);
@@ -657,32 +709,53 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     if (sl->calibrated) return GENPHI_OK;
     sl->k = -1;
     if (sl->tun.force_k == -1) { sl->calibrated = true; return GENPHI_OK; }
-    int last = 0;                                          // last cut whose lists exist
     const bool trace = std::getenv("GENPHI_TRACE") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    std::vector<unsigned> rnz;
-    std::vector<int> order, cnt;
+    // Every candidate cut in one go, without a word from the host in between: per cut a COUNTING launch (row lengths straight from the
+    // bitmaps), a scan that turns lengths into places (sparse_place_kernel), and the launch that writes the lists where they belong --
+    // the form every later sweep runs.  (The first version placed rows with an atomic cursor and synchronised after every cut: one
+    // same-address device-scope atomic per row is ~26 ns -- 1.9 of the 2.3 ms it took on genea140.)  A cut that turns out too dense
+    // voids itself (its rows do not fit the LDS of the writing launch, or its lists the arena): everything behind it sees empty lists.
+    int n_run = 0;
     int rc = launch_identity(sl, stream, err);
     if (rc) return rc;
     for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be kept as lists only when step s+1 is eligible too
         if (sl->tun.force_k >= 0 && s + 1 > sl->tun.force_k) break;
         const int n = sl->n_of[s + 1];
-        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, sl->n_ent[s] > 192ll * sl->n_of[s], stream, err);
+        const bool wide = sl->n_of[s] >= 4096;             // (list lengths are not known on the host yet)
+        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/true, /*calibrating=*/true);
         if (rc) return rc;
-        unsigned st[4] = {0, 0, 0, 0};
-        rnz.resize(n);
-        SP_TRY(hipMemcpyAsync(st, sl->stat + 4 * (s + 1), sizeof(st), hipMemcpyDeviceToHost, stream));
-        SP_TRY(hipMemcpyAsync(rnz.data(), sl->rnz[s + 1], static_cast<size_t>(n) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        SP_TRY(hipStreamSynchronize(stream));
-        if (st[2] != 0) break;                             // a row or the arena overflowed: too dense for lists
+        const unsigned long long stop_entries = sl->tun.force_k >= 0 ? ~0ull : static_cast<unsigned long long>(0.25 * static_cast<double>(n) * static_cast<double>(n));
+        hipLaunchKernelGGL(sparse_place_kernel, dim3(1), dim3(1024), 0, stream, sl->rowd[s + 1], n,
+                           static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu)), stop_entries, sl->stat + 4 * (s + 1), sl->stat + 3, static_cast<unsigned>(s + 1));
+        SP_TRY(hipGetLastError());
+        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/false, /*calibrating=*/true);
+        if (rc) return rc;
+        n_run = s + 1;
+    }
+    // one round trip: the counters of every cut and every row's number of non-zero entries
+    std::vector<unsigned> st(4 * (static_cast<size_t>(sl->S) + 1), 0u), rnz_all;
+    std::vector<size_t> rnz_at(sl->S + 1, 0);
+    size_t rnz_total = 0;
+    for (int c = 1; c <= n_run; ++c) { rnz_at[c] = rnz_total; rnz_total += static_cast<size_t>(sl->n_of[c]); }
+    rnz_all.resize(std::max<size_t>(rnz_total, 1));
+    SP_TRY(hipMemcpyAsync(st.data(), sl->stat, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    for (int c = 1; c <= n_run; ++c)
+        SP_TRY(hipMemcpyAsync(rnz_all.data() + rnz_at[c], sl->rnz[c], static_cast<size_t>(sl->n_of[c]) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    SP_TRY(hipStreamSynchronize(stream));
+    int last = 0;                                          // last cut whose lists are valid and sparse enough
+    std::vector<int> order, cnt;
+    std::vector<std::vector<int>> orders(sl->S + 1);
+    for (int s = 0; s < n_run; ++s) {
+        const int n = sl->n_of[s + 1];
+        if (st[4 * (s + 1) + 2] != 0) break;               // a row or the arena overflowed, or a cut before it was too dense: no lists
+        const unsigned *rnz = rnz_all.data() + rnz_at[s + 1];
         long long nnz = 0;
         unsigned longest = 0;
         for (int q = 0; q < n; ++q) { nnz += rnz[q]; longest = std::max(longest, rnz[q]); }
         sl->nnz[s + 1] = nnz;
-        sl->n_ent[s + 1] = static_cast<long long>(st[0]);
+        sl->n_ent[s + 1] = static_cast<long long>(st[4 * (s + 1) + 0]);
         sl->max_row[s + 1] = static_cast<int>(longest);
-        // the rows of cut s+1 by length, longest first (a counting sort; lengths are <= cap_cal): a launch per class of lengths, each
-        // with the LDS its rows need
+        // the rows of cut s+1 by length, longest first (a counting sort): a launch per class of lengths, each with the LDS its rows need
         order.resize(n);
         cnt.assign(static_cast<size_t>(longest) + 2, 0);
         for (int q = 0; q < n; ++q) cnt[longest - rnz[q] + 1]++;
@@ -692,22 +765,18 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         cl = {0, 0, 0, n};
         for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; else if (rnz[order[q]] > 256u) cl[2] = q + 1; else break; }
         cl[2] = std::max(cl[2], cl[1]);
-        SP_TRY(hipMemcpyAsync(sl->order[s + 1], order.data(), static_cast<size_t>(n) * sizeof(int), hipMemcpyHostToDevice, stream));
-        SP_TRY(hipStreamSynchronize(stream));
-        last = s + 1;
+        orders[s + 1] = order;
         const double dn = static_cast<double>(n);
-        if (trace) {
-            const auto t_now = std::chrono::steady_clock::now();
+        if (trace)
             std::fprintf(stderr, "[genphi trace]   sparse cut %2d: %6d members, %10lld non-zero (%.4f), %10lld list entries, longest row %5d, rows > 1024 / > 256: %d / %d; "
-                         "est. list step %.3f ms, dense step %.3f ms; calibrated in %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
-                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s), std::chrono::duration<double, std::milli>(t_now - t_prev).count());
-            t_prev = t_now;
-        }
-        if (sl->tun.force_k < 0) {
-            if (static_cast<double>(nnz) > sl->tun.max_permille / 1000.0 * dn * dn) break;
-            if (t_list_step(sl, s) > 2.0 * t_dense_step(sl, s) + 0.02) break;     // (it only gets denser)
-        }
+                         "est. list step %.3f ms, dense step %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
+                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s));
+        if (sl->tun.force_k < 0 && static_cast<double>(nnz) > sl->tun.max_permille / 1000.0 * dn * dn) break;
+        last = s + 1;
     }
+    for (int c = 1; c <= last; ++c)
+        SP_TRY(hipMemcpyAsync(sl->order[c], orders[c].data(), orders[c].size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    SP_TRY(hipStreamSynchronize(stream));                  // (`orders` goes out of scope)
     sl->calibrated = true;                                 // (from here on rows go where this run put them)
     if (last < 1) return GENPHI_OK;
     int k = last;
