@@ -187,6 +187,19 @@ def level_bytes(pl, sizes, both, esz=4.0, product_sweep=True, sparse=True):
     return alg, moved, in_place
 
 
+def settle_after_release(released_bytes):
+    """Wait until the driver has cleared device memory this process just released.  Released VRAM is wiped in the background with the copy
+    engines -- about 65 ms per GB -- and until that is done every device-to-host copy of the process runs at HALF its rate and a large
+    hipMalloc waits (profiles/microbench/free_then_copy.hip, out/r05_free_then_copy.out: 256 MB in 8.9 instead of 4.7 ms after a 1 GB
+    hipFree; the 40 GB result hipMalloc 0.3 ms -> ~1 s).  A measurement that follows the release of another workload's plan would time
+    that, not its own call.  Returns the seconds waited (reported on the line)."""
+    wait = min(8.0, float(released_bytes) / 12e9)
+    if wait > 0.02:
+        time.sleep(wait)
+        return wait
+    return 0.0
+
+
 def call_walls(ped, pro, device, with_d2h=True, reps=3):
     """Wall clock of one-shot gen.phi calls on a warm device -- what a caller of the drop-in API pays per call, the sweep being a small
     part of it: `first` = a plan nobody has seen (planning, upload, calibration of the sparse cuts, sweep, copy to the host, release),
@@ -197,14 +210,16 @@ def call_walls(ped, pro, device, with_d2h=True, reps=3):
         p2 = gen.Pedigree(ped.ind, ped.father, ped.mother, ped.sex)          # a pedigree object without cached plans
         t0 = time.perf_counter()
         if with_d2h:
-            gen.phi(p2, pro, device=device)
+            res = gen.phi(p2, pro, device=device)         # (kept until the clock is read: unmapping a 400 MB array is 15-20 ms of the interpreter's, not the call's)
         else:
             pl = gen.plan(p2, pro); pl.compute_device(device=device); pl.close()
         first.append((time.perf_counter() - t0) * 1e3)
+        res = None
         if with_d2h:
             t0 = time.perf_counter()
-            gen.phi(p2, pro, device=device)
+            res = gen.phi(p2, pro, device=device)
             repeat.append((time.perf_counter() - t0) * 1e3)
+            res = None
     out = {"first_ms": float(np.median(first)), "includes_copy_to_host": bool(with_d2h)}
     if repeat:
         out["repeat_ms"] = float(np.median(repeat))
@@ -260,8 +275,11 @@ def quick_workload(name, device, steps=5):
                 rec["real_traffic_frac"] = tj["hbm_bytes_per_launch"] * len(byt) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
+    released = pl.device_bytes
     pl.close()
+    settle_after_release(released)
     rec["call_wall"] = call_walls(ped, pro, device, with_d2h=n * n * 4 <= (2 << 30))
+    settle_after_release(released)                        # (the one-shot calls released their plans too)
     return rec
 
 
@@ -730,12 +748,17 @@ def main():
                                         "bandwidth figure); `real_traffic_frac`: measured HBM traffic")
         if not args.no_cpu_baseline and world == 1 and not f64:       # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ped, pro, sizes)
+        settled_s = 0.0
         if world == 1:
+            released = pl.device_bytes
             pl.close()                                     # (the measurements below make plans of their own: this one's memory first)
             pl = None
+            settled_s += settle_after_release(released)
         if world == 1 and not f64 and args.kernel == 0 and not args.no_sparse and not args.no_call_wall:
             # a one-shot call through the drop-in API (result left resident when it is too large to copy twice within the run)
             out["end_to_end"]["call_wall"] = call_walls(ped, pro, local_rank, with_d2h=n * n * 4 <= (2 << 30), reps=3 if n <= 20000 else 1)
+            settled_s += settle_after_release(released)
+            out["end_to_end"]["call_wall"]["waited_for_released_memory_s"] = round(settled_s, 2)
         if args.workload == "cfg4" and world == 1 and not f64 and args.kernel == 0 and not args.no_others and not args.no_sparse and not ab_hooks:
             # the other BASELINE.json configurations in the same process (each a few ms per sweep): driver-timed evidence for them
             others = {}

@@ -6,7 +6,7 @@
 // staging ring of genphi_result_to_host 60-100 ms to pin and 80 ms to unpin -- per call.  The reference has no counterpart
 // (its matrices are garbage-collected Julia arrays, src/compute.jl:291,301); this is the allocator a GC would be.
 //
-//   cached_malloc / cached_free    device blocks of released plans are kept (up to GENPHI_KEEP_MB, default 1024 MiB per
+//   cached_malloc / cached_free    device blocks of released plans are kept (up to GENPHI_KEEP_MB, default 8 GiB but at most 1/16 of the device's memory, per
 //                                  device; larger blocks go back to the driver at once) and handed to the next plan that asks
 //                                  for about that size.  The contents of a block are undefined, as with hipMalloc.
 //   cached_stream / release        non-blocking streams, kept idle between plans

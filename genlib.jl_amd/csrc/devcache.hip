@@ -16,8 +16,9 @@ struct Block {
 };
 
 struct DeviceState {
-    std::vector<Block> idle;               // kept blocks, unordered (a handful)
+    std::vector<Block> idle;               // kept blocks, oldest first (a handful)
     size_t idle_bytes = 0;
+    size_t keep_max = ~size_t(0);          // (set on first use: GENPHI_KEEP_MB, or 8 GiB but at most 1/16 of the device's memory)
     std::vector<hipStream_t> streams;
     PinnedRing ring;
 };
@@ -26,13 +27,32 @@ struct Cache {
     std::mutex mu;
     std::map<int, DeviceState> dev;        // (node-based: references stay valid)
     std::unordered_map<void *, std::pair<size_t, int>> live;      // blocks handed out: size, device
-    size_t keep_max;
+    bool keep_set = false;                 // GENPHI_KEEP_MB given
+    size_t keep_env = 0;
     Cache()
     {
         const char *e = std::getenv("GENPHI_KEEP_MB");
-        keep_max = (e ? static_cast<size_t>(std::max(0L, std::atol(e))) : size_t(1024)) << 20;
+        if (e) { keep_set = true; keep_env = static_cast<size_t>(std::max(0L, std::atol(e))) << 20; }
     }
+    // Why as much as 8 GiB: a block that goes back to the driver is cleared by it in the background with the copy engines (~65 ms per
+    // GB), and until that is done every device-to-host copy of the process runs at half its rate (profiles/microbench/free_then_copy.hip).
+    // A one-shot gen.phi whose plan does not fit the budget pays that on its own result copy, call after call (cfg3s, a 6 GB plan:
+    // its 400 MB copy 20.4 instead of 8.4 ms with the 1 GiB budget this cache started with).
+    size_t keep_max_of(DeviceState &d, int device);
 };
+
+size_t Cache::keep_max_of(DeviceState &d, int device)
+{
+    if (d.keep_max == ~size_t(0)) {
+        if (keep_set) d.keep_max = keep_env;
+        else {
+            size_t total = 0;
+            if (hipDeviceTotalMem(&total, device) != hipSuccess) { (void)hipGetLastError(); total = size_t(16) << 30; }
+            d.keep_max = std::min(size_t(8) << 30, total / 16);
+        }
+    }
+    return d.keep_max;
+}
 
 Cache &cache()
 {
@@ -68,8 +88,7 @@ hipError_t cached_malloc(void **ptr, size_t bytes)
             if (d.idle[k].bytes >= want && d.idle[k].bytes <= want + want / 4 && (best == d.idle.size() || d.idle[k].bytes < d.idle[best].bytes)) best = k;
         if (best < d.idle.size()) {
             const Block b = d.idle[best];
-            d.idle[best] = d.idle.back();
-            d.idle.pop_back();
+            d.idle.erase(d.idle.begin() + static_cast<std::ptrdiff_t>(best));
             d.idle_bytes -= b.bytes;
             c.live[b.ptr] = {b.bytes, device};
             *ptr = b.ptr;
@@ -92,6 +111,8 @@ hipError_t cached_free(void *ptr)
 {
     if (!ptr) return hipSuccess;
     Cache &c = cache();
+    std::vector<void *> evicted;                           // (the oldest kept blocks make room for the newest: what the next plan will ask for)
+    bool kept = false;
     {
         std::lock_guard<std::mutex> lock(c.mu);
         auto it = c.live.find(ptr);
@@ -100,14 +121,23 @@ hipError_t cached_free(void *ptr)
             const int device = it->second.second;
             c.live.erase(it);
             DeviceState &d = c.dev[device];
-            if (d.idle_bytes + bytes <= c.keep_max && d.idle.size() < 256) {
+            const size_t keep_max = c.keep_max_of(d, device);
+            if (bytes <= keep_max) {
+                while (!d.idle.empty() && (d.idle_bytes + bytes > keep_max || d.idle.size() >= 256)) {
+                    evicted.push_back(d.idle.front().ptr);
+                    d.idle_bytes -= d.idle.front().bytes;
+                    d.idle.erase(d.idle.begin());
+                }
                 d.idle.push_back({ptr, bytes});
                 d.idle_bytes += bytes;
-                return hipSuccess;
+                kept = true;
             }
         }
     }
-    return hipFree(ptr);
+    hipError_t e = hipSuccess;
+    for (void *q : evicted) { const hipError_t e2 = hipFree(q); if (e == hipSuccess) e = e2; }
+    if (!kept) { const hipError_t e2 = hipFree(ptr); if (e == hipSuccess) e = e2; }
+    return e;
 }
 
 hipError_t cached_stream(hipStream_t *st)
@@ -131,7 +161,7 @@ void cached_stream_release(hipStream_t st, int device)
     {
         std::lock_guard<std::mutex> lock(c.mu);
         DeviceState &d = c.dev[device];
-        if (c.keep_max > 0 && d.streams.size() < 8) { d.streams.push_back(st); return; }
+        if (c.keep_max_of(d, device) > 0 && d.streams.size() < 8) { d.streams.push_back(st); return; }
     }
     (void)hipStreamDestroy(st);
 }

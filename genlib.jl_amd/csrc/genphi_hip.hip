@@ -2019,6 +2019,7 @@ struct Tuning {
     int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
     int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
     int sparse_batch = 0;          // GENPHI_SPARSE_BATCH     A/B: list entries in flight per thread of a long row's workgroup, 4 or 8 (default 4; 8 measured slower)
+    int sparse_arena = 0;          // GENPHI_SPARSE_ARENA     test: entries the row-list arenas start with (default 4 Mi; small values exercise their growth)
     int d2h_chunk_mb = 0;          // GENPHI_D2H_CHUNK_MB     tuning: size of a pinned staging chunk of genphi_result_to_host (default 16, 4 for results below 2 GB)
     int sparse_classes = -1;       // GENPHI_SPARSE_CLASSES   A/B + test: 1 / 0 = a row-list step is always / never one launch per class of row lengths (default: where lengths differ much)
 };
@@ -2036,7 +2037,7 @@ static const char *const kTuningNames[] = {
     "GENPHI_STAY_FAMILY", "GENPHI_MAX_GROUP", "GENPHI_MAX_RUN", "GENPHI_FULL_BS", "GENPHI_NO_IDENTITY", "GENPHI_CERT_MIN_EXP", "GENPHI_DBG_STEP",
     "GENPHI_NO_FAST", "GENPHI_MAX_CPT", "GENPHI_FAST_NT", "GENPHI_WIDE_ROUTE", "GENPHI_TT_NOALIGN", "GENPHI_NO_SHARD_PRUNE", "GENPHI_SHARD_FORCE",
     "GENPHI_SHARD_PRUNE_MIN_STEP", "GENPHI_NO_SMALL", "GENPHI_NO_GRAPH", "GENPHI_D2H_THREADS", "GENPHI_D2H_PAGEABLE", "GENPHI_D2H_SYM", "GENPHI_D2H_TILE",
-    "GENPHI_D2H_CHUNK_MB", "GENPHI_TEST_FAIL_ALLOC", "GENPHI_SPARSE_K", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_BATCH"};
+    "GENPHI_D2H_CHUNK_MB", "GENPHI_TEST_FAIL_ALLOC", "GENPHI_SPARSE_K", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_BATCH", "GENPHI_SPARSE_ARENA"};
 
 // the settings of a plan: from a genphi_tuning when one is given, else from the environment -- which the library reads only under
 // GENPHI_ENV_HOOKS=1 (planner.h: env_hook)
@@ -2105,6 +2106,7 @@ static Tuning tuning_from(const genphi_tuning *tu)
     t.sparse_classes = geti("GENPHI_SPARSE_CLASSES", -1);
     t.d2h_chunk_mb = geti("GENPHI_D2H_CHUNK_MB", 0);
     t.sparse_batch = geti("GENPHI_SPARSE_BATCH", 0);
+    t.sparse_arena = geti("GENPHI_SPARSE_ARENA", 0);
     return t;
 }
 
@@ -2201,6 +2203,7 @@ struct genphi_plan {
     long long graph_key[5] = {0, 0, 0, 0, 0}, eager_key[5] = {0, 0, 0, 0, 0};
     long long alloc_gen = 1;
     bool level_bufs_ready = false;         // buf[] / psi_p exist (ensure_level_buffers)
+    int level_bufs_from = 0;               // ... buf[] sized for the dense matrices of cuts >= this one (the cuts before it live as row lists)
     int alloc_count = 0;                   // device allocations of uploads so far (GENPHI_TEST_FAIL_ALLOC)
     char *scratch = nullptr;               // genphi_result_sums / _entries staging (grown on demand)
     size_t scratch_bytes = 0;
@@ -2698,12 +2701,14 @@ static int upload_plan_impl(genphi_plan *p, int device)
 
 // The Float32 level matrices (ping-pong buffers, the compacted parent matrix of the WIDE steps): allocated by
 // the first Float32 sweep, not by the upload -- a Float64-storage sweep (gen.f, pairwise phi) never touches them.
-static int ensure_level_buffers_impl(genphi_plan *p)
+static int ensure_level_buffers_impl(genphi_plan *p, int first_cut)
 {
     const Plan &pl = p->plan;
-    // ping-pong buffers for the intermediate cuts 0..L-2
+    // ping-pong buffers for the intermediate cuts first_cut..L-2 (the cuts before live as row lists, sparse_levels.hip: genea140's widest
+    // cuts -- 13,654 members, 2 x 745 MB of level buffers -- are among them; its first dense cut has 4,8xx: allocating, clearing and
+    // giving back the large pair was 0.5 ms of every one-shot call, and released VRAM slows the next copies down, devcache.h)
     size_t need[2] = {0, 0};
-    for (int c = 0; c + 1 < pl.n_levels; ++c) {
+    for (int c = first_cut; c + 1 < pl.n_levels; ++c) {
         // a cut stored by slot (the cuts of an in-place run of WIDE steps): P + 1 rows of pitch P = ld[c]
         const bool by_slot = pl.steps[c].src_slots;
         const size_t fl = static_cast<size_t>(((by_slot ? static_cast<int64_t>(pl.steps[c].P) : pl.cut_sizes[c]) + 1) * pl.ld[c]) + kTailPadFloats;
@@ -2718,6 +2723,8 @@ static int ensure_level_buffers_impl(genphi_plan *p)
         }
         p->buf_floats[b] = need[b];
     }
+    p->level_bufs_from = first_cut;
+    if (p->level_bufs_ready) return GENPHI_OK;         // (only the pair was replaced: a sweep that needs earlier cuts densely after all)
     // WIDE steps: the compacted parent matrix and its rows' certificates
     {
         size_t need_p = 0, need_c = 0;
@@ -2747,10 +2754,15 @@ static int ensure_level_buffers_impl(genphi_plan *p)
     p->level_bufs_ready = true;
     return GENPHI_OK;
 }
-static int ensure_level_buffers(genphi_plan *p)
+static int ensure_level_buffers(genphi_plan *p, int first_cut)
 {
-    if (p->level_bufs_ready) return GENPHI_OK;
-    const int rc = ensure_level_buffers_impl(p);
+    if (p->level_bufs_ready && p->level_bufs_from <= first_cut) return GENPHI_OK;
+    if (p->level_bufs_ready) {                        // e.g. GENPHI_FLAG_NO_SPARSE on a plan whose sweeps ran their leading cuts on lists
+        drop_graph(p);
+        (void)hipStreamSynchronize(p->stream);
+        for (int b = 0; b < 2; ++b) { if (p->buf[b]) (void)genphi::cached_free(p->buf[b]); p->buf[b] = nullptr; p->buf_floats[b] = 0; }
+    }
+    const int rc = ensure_level_buffers_impl(p, first_cut);
     if (rc != GENPHI_OK) {                            // same rule as upload_plan: no half-allocated plan survives a failure
         const std::string keep = g_last_error;
         free_device(p);
@@ -3374,6 +3386,7 @@ static int ensure_sparse_levels(genphi_plan *p, int kernel, PhaseTrace &trace)
         if (p->tun.sparse_chunk > 0) stn.chunk_cols = p->tun.sparse_chunk;
         stn.classes = p->tun.sparse_classes;
         if (p->tun.sparse_batch == 4 || p->tun.sparse_batch == 8) stn.long_batch = p->tun.sparse_batch;
+        if (p->tun.sparse_arena > 0) stn.first_entries = p->tun.sparse_arena;
         std::string serr;
         p->sparse = genphi::sparse_levels_create(pl, S, dev, stn, p->stream, serr);
         if (p->sparse) {
@@ -3405,10 +3418,6 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
     const int64_t N = pl.n_pro, ldN = pl.ld[L - 1], n_rows = r1 - r0;
     int rc = ensure_doubles(&p->result64, &p->result64_doubles, static_cast<size_t>(n_rows * ldN));
     if (rc) return rc;
-    size_t need[2] = {0, 0};
-    for (int c = 0; c + 1 < L; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]));
-    for (int b = 0; b < 2; ++b)
-        if (need[b]) { rc = ensure_doubles(&p->buf64[b], &p->buf64_doubles[b], need[b]); if (rc) return rc; }
     // storage member of each resident row (the last cut may be stored in [dragged, new] order)
     std::vector<int> srow(n_rows), orow(n_rows);
     for (int64_t k = 0; k < n_rows; ++k) { srow[k] = pl.final_perm.empty() ? static_cast<int>(r0 + k) : pl.final_perm[r0 + k]; orow[k] = static_cast<int>(k); }
@@ -3442,6 +3451,12 @@ static int compute_f64(genphi_plan *p, int64_t r0, int64_t r1, int kernel, genph
         if (rc) return rc;
     }
     const int sparse_k = (kernel == 0 && p->sparse && !no_sparse) ? genphi::sparse_levels_k(p->sparse) : -1;
+    {   // Float64 level matrices of the cuts that exist as matrices (cuts 0..sparse_k live as row lists): genea140 2 x 1.5 GB -> 2 x 0.2
+        size_t need[2] = {0, 0};
+        for (int c = sparse_k + 1; c + 1 < L; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>((pl.cut_sizes[c] + 1) * pl.ld[c]));
+        for (int b = 0; b < 2; ++b)
+            if (need[b]) { rc = ensure_doubles(&p->buf64[b], &p->buf64_doubles[b], need[b]); if (rc) return rc; }
+    }
     const int64_t n0 = pl.cut_sizes[0], ld0 = pl.ld[0];
     if (timing) HIP_TRY(hipEventRecord(p->events[0], p->stream));
     if (sparse_k < 0) {
@@ -3559,13 +3574,13 @@ int genphi_compute_device(genphi_plan *p, const genphi_opts *opts, genphi_stats 
     }
     if (p->popt.indices_only) return fail(GENPHI_ERR_ARG, "internal: an indices-only plan serves Float64-storage sweeps only");
     p->stay_active = kernel != 1;             // the per-entry kernel sweep (kernel = 1) knows no slots: every level is written compactly
-    rc = ensure_level_buffers(p);
-    if (rc) return rc;
-    trace.mark("ensure_level_buffers");
     const int n_steps = L - 1;
     rc = ensure_sparse_levels(p, kernel, trace);
     if (rc) return rc;
     const int sparse_k = (kernel == 0 && p->sparse && !(opts && (opts->flags & GENPHI_FLAG_NO_SPARSE))) ? genphi::sparse_levels_k(p->sparse) : -1;
+    rc = ensure_level_buffers(p, sparse_k + 1);       // (cuts 0..sparse_k never exist as matrices)
+    if (rc) return rc;
+    trace.mark("ensure_level_buffers");
     if (timing && n_steps + 2 > GENPHI_MAX_STAT_LEVELS) return fail(GENPHI_ERR_ARG, "too many levels for timing stats");
     if (timing) {
         while (static_cast<int>(p->events.size()) < n_steps + 3) {
@@ -4123,6 +4138,7 @@ int genphi_result_to_host(genphi_plan *p, float *out)
             if (e != hipSuccess) return fail(GENPHI_ERR_DEVICE, std::string("genphi_result_to_host: ") + hipGetErrorString(e));
         return GENPHI_OK;
     }
+    const bool d2h_stats = genphi::env_hook("GENPHI_D2H_STATS") != nullptr;
     auto copy_block = [&](int t) {
         const size_t r0 = rows * t / n_thr, r1 = rows * (t + 1) / n_thr;
         if (r1 == r0) return;
@@ -4143,13 +4159,19 @@ int genphi_result_to_host(genphi_plan *p, float *out)
                                     row_bytes, b - a, hipMemcpyDeviceToHost, st);
         };
         e = issue(0);
+        double t_wait = 0.0, t_host = 0.0;
+        auto clk = [] { return std::chrono::steady_clock::now(); };
         for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+            const auto t0 = clk();
             e = hipStreamSynchronize(st);               // chunk c has landed in pb[c & 1]
             if (e != hipSuccess) break;
             if (c + 1 < n_chunks) e = issue(c + 1);     // the DMA engine fills the other buffer meanwhile
+            const auto t1 = clk();
             const size_t a = r0 + c * chunk_rows, b = std::min(r1, a + chunk_rows);
             std::memcpy(out + a * N, pb[c & 1], (b - a) * row_bytes);
+            if (d2h_stats) { t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_host += std::chrono::duration<double, std::milli>(clk() - t1).count(); }
         }
+        if (d2h_stats) std::fprintf(stderr, "[genphi d2h] thread %d: %zu chunks, waiting for the DMA %.2f ms, copying into the caller's array %.2f ms\n", t, n_chunks, t_wait, t_host);
         errs[t] = e;
     };
     if (n_thr == 1) copy_block(0);

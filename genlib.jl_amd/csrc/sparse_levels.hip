@@ -323,7 +323,8 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
 }
 
 // places of the rows of a cut from their lengths (calibration run): rowd[i].x = sum of rowd[j].y over j < i; the total goes to stat[0];
-// a cut whose lists do not fit the arena is voided (every length 0, overflow flag).  One workgroup: a cut has < 65,535 rows.
+// a cut whose lists do not fit the arena is voided (every length 0; flag 8 and the entries it needs in stat[1]: the host enlarges the
+// arena and runs the cut again).  One workgroup: a cut has < 65,535 rows.
 __global__ void __launch_bounds__(1024) sparse_place_kernel(uint2 *rowd, int n, unsigned ent_cap, unsigned long long stop_entries, unsigned *stat,
                                                             unsigned *stop, unsigned level)
 {
@@ -354,7 +355,10 @@ __global__ void __launch_bounds__(1024) sparse_place_kernel(uint2 *rowd, int n, 
     }
     if (tid == 0) {
         stat[0] = ok ? static_cast<unsigned>(total) : 0u;
-        if (!ok) atomicOr(&stat[2], 1u);
+        if (!ok) {
+            stat[1] = total > 0xffffffffull ? 0xffffffffu : static_cast<unsigned>(total);
+            atomicOr(&stat[2], 8u);
+        }
         // a void cut ends the run here; one too dense to be worth a list step behind it (its lists alone are a quarter of a dense level's
         // bytes) is still written -- it may be the last sparse one -- and ends the run behind it
         if (!ok || stat[2] != 0u) *stop = level;
@@ -463,7 +467,9 @@ struct SparseLevels {
     std::vector<unsigned *> rnz;
     std::vector<int *> order;
     std::vector<std::array<int, 4>> cls;
-    size_t ent_cap = 0;
+    size_t ent_cap[2] = {0, 0};      // entries each arena holds: small at first, enlarged by the calibration run where a cut needs it
+    size_t ent_max = 0;              // ... up to this many (a cut that needs more is too dense to stay sparse)
+    int n_grown = 0;                 // (trace) how often the calibration run enlarged an arena
     unsigned *stat = nullptr;        // 4 words per cut
     unsigned *stat_host = nullptr;   // pinned copy of them, fetched at the end of a sweep
     std::vector<long long> nnz;      // non-zero entries of Psi_c per cut 0..S (-1 unknown)
@@ -594,9 +600,17 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     const double share = tun.force_k >= 0 ? 1.0 : std::min(1.0, std::max(1, tun.max_permille) / 1000.0);
     double want = 3.0 * share * static_cast<double>(n_max) * static_cast<double>(n_max) + 8.0 * n_max + 1024.0;
     want = std::min(want, 4.0e9);                      // (32-bit cursor)
-    sl->ent_cap = static_cast<size_t>(want);
-    for (int b = 0; b < 2; ++b)
-        if (cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), sl->ent_cap * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row-list arena) failed");
+    // `want` is the most an arena may grow to, not what it starts with: the lists of the leading cuts are tiny (genea140: 0.2 k ... 11 M
+    // entries where `want` is 110 M), and a block allocated for the worst case has to be given back after the calibration run -- the
+    // driver clears released VRAM with the copy engines, and for ~65 ms per GB released every device-to-host copy of the process runs
+    // at HALF its rate (profiles/microbench/free_then_copy.hip: 256 MB in 8.9 instead of 4.7 ms; a one-shot gen.phi with a 400 MB
+    // result right after genea140: 20.5 instead of 8.5 ms for the copy).
+    sl->ent_max = static_cast<size_t>(want);
+    const size_t first = std::min(sl->ent_max, std::max<size_t>(static_cast<size_t>(std::max(64, tun.first_entries)), static_cast<size_t>(sl->n_ch[0]) + 64));
+    for (int b = 0; b < 2; ++b) {
+        sl->ent_cap[b] = first;
+        if (cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), sl->ent_cap[b] * sizeof(uint2)) != hipSuccess) return fail("hipMalloc (row-list arena) failed");
+    }
     size_t rowd_total = 0, fm_total = 0;
     auto pad32 = [](int n) { return (static_cast<size_t>(n) + 32) / 32 * 32; };
     for (int c = 0; c < S; ++c) { rowd_total += pad32(sl->n_of[c]); fm_total += pad32(sl->n_of[c + 1]); }
@@ -613,10 +627,11 @@ SparseLevels *sparse_levels_create(const Plan &plan, int S, const std::vector<Sp
     if (cached_pinned(reinterpret_cast<void **>(&sl->stat_host), 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned)) != hipSuccess)
         return fail("hipHostMalloc (counters) failed");
     std::memset(sl->stat_host, 0, 4 * (static_cast<size_t>(S) + 1) * sizeof(unsigned));
-    sl->bytes = static_cast<double>(total) + 2.0 * sl->ent_cap * sizeof(uint2) + static_cast<double>(rowd_total * sizeof(uint2) + fm_total * sizeof(unsigned));
+    sl->bytes = static_cast<double>(total) + static_cast<double>((sl->ent_cap[0] + sl->ent_cap[1]) * sizeof(uint2)) +
+                static_cast<double>(rowd_total * sizeof(uint2) + fm_total * sizeof(unsigned));
     sl->cap_cal = std::min(8192, (n_max + 63) / 64 * 64);
     trace.mark("  sparse: arenas");
-    if (static_cast<size_t>(sl->n_ch[0]) > sl->ent_cap) return fail("sparse levels: arena smaller than the first cut");
+    if (static_cast<size_t>(sl->n_ch[0]) > sl->ent_cap[0]) return fail("sparse levels: arena smaller than the first cut");
     return sl;
 }
 
@@ -653,7 +668,7 @@ static SpArgs args_for(const SparseLevels *sl, int s)
         a.rnz_out = sl->rnz[s + 1];
     }
     a.count_only = 0;
-    a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu));
+    a.ent_cap = static_cast<unsigned>(std::min<size_t>(sl->ent_cap[(s + 1) & 1], 0xffffffffu));
     return a;
 }
 
@@ -715,65 +730,114 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     // the form every later sweep runs.  (The first version placed rows with an atomic cursor and synchronised after every cut: one
     // same-address device-scope atomic per row is ~26 ns -- 1.9 of the 2.3 ms it took on genea140.)  A cut that turns out too dense
     // voids itself (its rows do not fit the LDS of the writing launch, or its lists the arena): everything behind it sees empty lists.
-    int n_run = 0;
     int rc = launch_identity(sl, stream, err);
     if (rc) return rc;
-    for (int s = 0; s + 1 < sl->S; ++s) {                  // cut s+1 may be kept as lists only when step s+1 is eligible too
-        if (sl->tun.force_k >= 0 && s + 1 > sl->tun.force_k) break;
-        const int n = sl->n_of[s + 1];
-        const bool wide = sl->n_of[s] >= 4096;             // (list lengths are not known on the host yet)
-        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/true, /*calibrating=*/true);
-        if (rc) return rc;
-        const unsigned long long stop_entries = sl->tun.force_k >= 0 ? ~0ull : static_cast<unsigned long long>(0.25 * static_cast<double>(n) * static_cast<double>(n));
-        hipLaunchKernelGGL(sparse_place_kernel, dim3(1), dim3(1024), 0, stream, sl->rowd[s + 1], n,
-                           static_cast<unsigned>(std::min<size_t>(sl->ent_cap, 0xffffffffu)), stop_entries, sl->stat + 4 * (s + 1), sl->stat + 3, static_cast<unsigned>(s + 1));
-        SP_TRY(hipGetLastError());
-        rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/false, /*calibrating=*/true);
-        if (rc) return rc;
-        n_run = s + 1;
-    }
-    // one round trip: the counters of every cut and every row's number of non-zero entries
+    const int n_cand = sl->tun.force_k >= 0 ? std::min(sl->S - 1, sl->tun.force_k) : sl->S - 1;   // cuts 1..n_cand may be kept as lists
     std::vector<unsigned> st(4 * (static_cast<size_t>(sl->S) + 1), 0u), rnz_all;
     std::vector<size_t> rnz_at(sl->S + 1, 0);
     size_t rnz_total = 0;
-    for (int c = 1; c <= n_run; ++c) { rnz_at[c] = rnz_total; rnz_total += static_cast<size_t>(sl->n_of[c]); }
+    for (int c = 1; c <= n_cand; ++c) { rnz_at[c] = rnz_total; rnz_total += static_cast<size_t>(sl->n_of[c]); }
     rnz_all.resize(std::max<size_t>(rnz_total, 1));
-    SP_TRY(hipMemcpyAsync(st.data(), sl->stat, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    for (int c = 1; c <= n_run; ++c)
-        SP_TRY(hipMemcpyAsync(rnz_all.data() + rnz_at[c], sl->rnz[c], static_cast<size_t>(sl->n_of[c]) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    SP_TRY(hipStreamSynchronize(stream));
     int last = 0;                                          // last cut whose lists are valid and sparse enough
     std::vector<int> order, cnt;
     std::vector<std::vector<int>> orders(sl->S + 1);
-    for (int s = 0; s < n_run; ++s) {
-        const int n = sl->n_of[s + 1];
-        if (st[4 * (s + 1) + 2] != 0) break;               // a row or the arena overflowed, or a cut before it was too dense: no lists
-        const unsigned *rnz = rnz_all.data() + rnz_at[s + 1];
-        long long nnz = 0;
-        unsigned longest = 0;
-        for (int q = 0; q < n; ++q) { nnz += rnz[q]; longest = std::max(longest, rnz[q]); }
-        sl->nnz[s + 1] = nnz;
-        sl->n_ent[s + 1] = static_cast<long long>(st[4 * (s + 1) + 0]);
-        sl->max_row[s + 1] = static_cast<int>(longest);
-        // the rows of cut s+1 by length, longest first (a counting sort): a launch per class of lengths, each with the LDS its rows need
-        order.resize(n);
-        cnt.assign(static_cast<size_t>(longest) + 2, 0);
-        for (int q = 0; q < n; ++q) cnt[longest - rnz[q] + 1]++;
-        for (unsigned v = 0; v <= longest; ++v) cnt[v + 1] += cnt[v];
-        for (int q = 0; q < n; ++q) order[cnt[longest - rnz[q]]++] = q;
-        std::array<int, 4> &cl = sl->cls[s + 1];
-        cl = {0, 0, 0, n};
-        for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; else if (rnz[order[q]] > 256u) cl[2] = q + 1; else break; }
-        cl[2] = std::max(cl[2], cl[1]);
-        orders[s + 1] = order;
-        const double dn = static_cast<double>(n);
-        if (trace)
-            std::fprintf(stderr, "[genphi trace]   sparse cut %2d: %6d members, %10lld non-zero (%.4f), %10lld list entries, longest row %5d, rows > 1024 / > 256: %d / %d; "
-                         "est. list step %.3f ms, dense step %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
-                         sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s));
-        if (sl->tun.force_k < 0 && static_cast<double>(nnz) > sl->tun.max_permille / 1000.0 * dn * dn) break;
-        last = s + 1;
+    // The arenas start small (sparse_levels_create).  A cut whose lists do not fit voids itself and names the entries it needs; the host
+    // then enlarges the arena that cut is written to (the other one holds its source), gives the other one room for the cut behind it
+    // (moving the live lists), and the run resumes AT that cut: `from` = the first cut of the current leg.
+    for (int from = 1; from <= n_cand;) {
+        for (int s = from - 1; s < n_cand; ++s) {          // cut s+1 may be kept as lists only when step s+1 is eligible too
+            const int n = sl->n_of[s + 1];
+            const bool wide = sl->n_of[s] >= 4096;         // (list lengths are not known on the host yet)
+            rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/true, /*calibrating=*/true);
+            if (rc) return rc;
+            const unsigned long long stop_entries = sl->tun.force_k >= 0 ? ~0ull : static_cast<unsigned long long>(0.25 * static_cast<double>(n) * static_cast<double>(n));
+            hipLaunchKernelGGL(sparse_place_kernel, dim3(1), dim3(1024), 0, stream, sl->rowd[s + 1], n,
+                               static_cast<unsigned>(std::min<size_t>(sl->ent_cap[(s + 1) & 1], 0xffffffffu)), stop_entries, sl->stat + 4 * (s + 1), sl->stat + 3,
+                               static_cast<unsigned>(s + 1));
+            SP_TRY(hipGetLastError());
+            rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/false, /*calibrating=*/true);
+            if (rc) return rc;
+        }
+        // one round trip per leg: the counters of every cut and every row's number of non-zero entries
+        SP_TRY(hipMemcpyAsync(st.data(), sl->stat, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        for (int c = from; c <= n_cand; ++c)
+            SP_TRY(hipMemcpyAsync(rnz_all.data() + rnz_at[c], sl->rnz[c], static_cast<size_t>(sl->n_of[c]) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipStreamSynchronize(stream));
+        int grow_at = 0;
+        for (int s = from - 1; s < n_cand; ++s) {
+            const int n = sl->n_of[s + 1];
+            const unsigned flags = st[4 * (s + 1) + 2];
+            if (flags == 8u && static_cast<size_t>(st[4 * (s + 1) + 1]) + 64 <= sl->ent_max) { grow_at = s + 1; break; }   // only the arena was too small
+            if (flags != 0u) break;                        // a row overflowed, or a cut before it was too dense: no lists
+            const unsigned *rnz = rnz_all.data() + rnz_at[s + 1];
+            long long nnz = 0;
+            unsigned longest = 0;
+            for (int q = 0; q < n; ++q) { nnz += rnz[q]; longest = std::max(longest, rnz[q]); }
+            sl->nnz[s + 1] = nnz;
+            sl->n_ent[s + 1] = static_cast<long long>(st[4 * (s + 1) + 0]);
+            sl->max_row[s + 1] = static_cast<int>(longest);
+            // the rows of cut s+1 by length, longest first (a counting sort): a launch per class of lengths, each with the LDS its rows need
+            order.resize(n);
+            cnt.assign(static_cast<size_t>(longest) + 2, 0);
+            for (int q = 0; q < n; ++q) cnt[longest - rnz[q] + 1]++;
+            for (unsigned v = 0; v <= longest; ++v) cnt[v + 1] += cnt[v];
+            for (int q = 0; q < n; ++q) order[cnt[longest - rnz[q]]++] = q;
+            std::array<int, 4> &cl = sl->cls[s + 1];
+            cl = {0, 0, 0, n};
+            for (int q = 0; q < n; ++q) { if (rnz[order[q]] > 1024u) cl[1] = q + 1; else if (rnz[order[q]] > 256u) cl[2] = q + 1; else break; }
+            cl[2] = std::max(cl[2], cl[1]);
+            orders[s + 1] = order;
+            const double dn = static_cast<double>(n);
+            if (trace)
+                std::fprintf(stderr, "[genphi trace]   sparse cut %2d: %6d members, %10lld non-zero (%.4f), %10lld list entries, longest row %5d, rows > 1024 / > 256: %d / %d; "
+                             "est. list step %.3f ms, dense step %.3f ms\n", s + 1, n, sl->nnz[s + 1], static_cast<double>(sl->nnz[s + 1]) / (dn * dn), sl->n_ent[s + 1],
+                             sl->max_row[s + 1], cl[1], cl[2], t_list_step(sl, s), t_dense_step(sl, s));
+            if (sl->tun.force_k < 0 && static_cast<double>(nnz) > sl->tun.max_permille / 1000.0 * dn * dn) break;
+            last = s + 1;
+        }
+        if (grow_at == 0) break;
+        {
+            const int c = grow_at, b = c & 1;
+            const size_t need = static_cast<size_t>(st[4 * c + 1]);
+            // Large lists only where they can pay: when the estimated times already say that cut c as lists (a list step into it and the dense
+            // matrix of cut c+1 from it) loses against stopping at cut c-1, the run ends here instead of allocating for it (cfg4's cut 6: 2.4 GB).
+            if (sl->tun.force_k < 0 && c >= 2 && need * sizeof(uint2) > (size_t(256) << 20)) {
+                const long long keep = sl->n_ent[c];
+                sl->n_ent[c] = static_cast<long long>(need);
+                const bool pays = t_list_step(sl, c - 1) + t_dense_from_lists(sl, c) < t_dense_from_lists(sl, c - 1) + t_dense_step(sl, c);
+                sl->n_ent[c] = keep;
+                if (trace) std::fprintf(stderr, "[genphi trace]   sparse cut %2d needs %zu list entries: %s\n", c, need, pays ? "arena enlarged" : "not worth its lists, the run ends");
+                if (!pays) break;
+            }
+            (void)cached_free(sl->ent[b]);                 // (holds cut c-2: dead)
+            sl->ent[b] = nullptr;
+            const size_t cap_b = std::min(sl->ent_max, need + need / 8 + 64);
+            SP_TRY(cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), cap_b * sizeof(uint2)));
+            sl->bytes += static_cast<double>(cap_b * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b] * sizeof(uint2));
+            sl->ent_cap[b] = cap_b;
+            if (c < n_cand) {                              // room for the cut behind it in the other arena (lists grow up to ~4 x per cut, less and less)
+                const size_t dense_next = static_cast<size_t>(sl->n_of[c + 1]) * static_cast<size_t>(c + 2 <= sl->S ? sl->n_of[c + 2] : sl->n_of[c + 1]) + 64;
+                const size_t cap_o = std::min(std::min(sl->ent_max, dense_next), 3 * need);
+                if (cap_o > sl->ent_cap[b ^ 1]) {
+                    uint2 *bigger = nullptr;
+                    SP_TRY(cached_malloc(reinterpret_cast<void **>(&bigger), cap_o * sizeof(uint2)));
+                    const size_t live = static_cast<size_t>(sl->n_ent[c - 1]);       // cut c-1: the source of the leg to come
+                    SP_TRY(hipMemcpyAsync(bigger, sl->ent[b ^ 1], live * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+                    SP_TRY(hipStreamSynchronize(stream));
+                    (void)cached_free(sl->ent[b ^ 1]);
+                    sl->ent[b ^ 1] = bigger;
+                    sl->bytes += static_cast<double>(cap_o * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b ^ 1] * sizeof(uint2));
+                    sl->ent_cap[b ^ 1] = cap_o;
+                }
+            }
+            ++sl->n_grown;
+            // the counters of cuts c.. and the stop word start over
+            SP_TRY(hipMemsetAsync(sl->stat + 4 * c, 0, 4 * static_cast<size_t>(sl->S + 1 - c) * sizeof(unsigned), stream));
+            SP_TRY(hipMemsetAsync(sl->stat + 3, 0, sizeof(unsigned), stream));
+            from = c;
+        }
     }
+    if (trace && sl->n_grown) std::fprintf(stderr, "[genphi trace]   sparse: arenas enlarged %d times (%zu + %zu entries)\n", sl->n_grown, sl->ent_cap[0], sl->ent_cap[1]);
     for (int c = 1; c <= last; ++c)
         SP_TRY(hipMemcpyAsync(sl->order[c], orders[c].data(), orders[c].size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SP_TRY(hipStreamSynchronize(stream));                  // (`orders` goes out of scope)
@@ -803,14 +867,13 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         for (int c = 0; c <= k; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>(sl->n_ent[c]) + 64);
         SP_TRY(hipStreamSynchronize(stream));
         for (int b = 0; b < 2; ++b) {
-            if (need[b] * 2 > sl->ent_cap) { need[b] = sl->ent_cap; continue; }      // (not worth a reallocation)
+            if (need[b] * 2 > sl->ent_cap[b]) continue;    // (not worth a reallocation)
             (void)cached_free(sl->ent[b]);
             sl->ent[b] = nullptr;
             SP_TRY(cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), need[b] * sizeof(uint2)));
+            sl->bytes += static_cast<double>(need[b] * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b] * sizeof(uint2));
+            sl->ent_cap[b] = need[b];
         }
-        sl->bytes -= 2.0 * sl->ent_cap * sizeof(uint2);
-        sl->bytes += static_cast<double>((need[0] + need[1]) * sizeof(uint2));
-        sl->ent_cap = std::min(need[0], need[1]);          // (what the kernels check writes against)
     }
     if (trace) std::fprintf(stderr, "[genphi trace]   sparse cuts 0..%d\n", k);
     return GENPHI_OK;

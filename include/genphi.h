@@ -251,7 +251,7 @@ int genphi_branching(int64_t n_ind, const int64_t *ind, const int64_t *father, c
                      const int64_t *ancestors, int64_t *n_out, int64_t **ind_out, int64_t **father_out,
                      int64_t **mother_out, int64_t **sex_out);
 
-/* What the library keeps between calls, per process: device blocks of released plans (up to GENPHI_KEEP_MB, default 1024 MiB per
+/* What the library keeps between calls, per process: device blocks of released plans (up to GENPHI_KEEP_MB, default 8 GiB but at most 1/16 of the device's memory, per
  * device, handed to the next plan instead of hipMalloc / hipFree), idle streams, the pinned staging ring of genphi_result_to_host,
  * and the device side + pinned buffer of the last genphi_sparse_phi call (up to GENPHI_SPARSE_KEEP_MB, default 1024).  A one-shot
  * gen.phi call on a mid-size pedigree otherwise spends most of its time in the allocator.  genphi_release_cached gives all of it

@@ -18,7 +18,7 @@ KNOBS = ["GENPHI_LDS_CAP_FLOATS", "GENPHI_FULL_MAX_FLOATS", "GENPHI_CERT_MIN_EXP
          "GENPHI_MAX_CPT", "GENPHI_NO_SMALL", "GENPHI_NO_SHARD_PRUNE", "GENPHI_MAX_GROUP", "GENPHI_WIDE_ROUTE", "GENPHI_MAX_RUN",
          "GENPHI_NO_STAY", "GENPHI_STAY_HEADROOM", "GENPHI_STAY_MEM_PCT", "GENPHI_STAY_SCATTER", "GENPHI_STAY_TWO_PASS",
          "GENPHI_STAY_NARROW", "GENPHI_STAY_NARROW_MIN", "GENPHI_STAY_MIN_RATIO_PCT", "GENPHI_STAY_SCALAR_T", "GENPHI_STAY_OVERHEAD_K", "GENPHI_STAY_LAST", "GENPHI_COLPERM_PLAIN", "GENPHI_STAY_TILE", "GENPHI_SPARSE_NO_FUSED",
-         "GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_CHUNK"]
+         "GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_CLASSES", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_ARENA"]
 
 
 def make_case(case):
@@ -100,6 +100,8 @@ def make_case(case):
             env["GENPHI_SPARSE_CLASSES"] = str(int(r5.choice([0, 1])))
         if r5.random() < 0.4:
             env["GENPHI_SPARSE_CHUNK"] = str(int(r5.choice([1024, 2048])))
+        if r5.random() < 0.5:                                       # (small arenas: the calibration run enlarges them cut by cut)
+            env["GENPHI_SPARSE_ARENA"] = str(int(r5.choice([64, 200, 1000, 20000])))
     elif r5.random() < 0.3:
         env["GENPHI_SPARSE_K"] = "-1"
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env

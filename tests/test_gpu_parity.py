@@ -1525,7 +1525,7 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
     stores only `coefficient > 0.` for the same reason, src/compute.jl:391-394): bit-equal to the oracle and to the same plan run
     densely (GENPHI_FLAG_NO_SPARSE), by calibration and with the last sparse cut forced, with row shards and graph replay."""
     from genlib_jl_amd import synth
-    for name in ("GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_CHUNK"):
+    for name in ("GENPHI_SPARSE_K", "GENPHI_SPARSE_MIN_CUT", "GENPHI_SPARSE_PERMILLE", "GENPHI_SPARSE_CHUNK", "GENPHI_SPARSE_ARENA"):
         monkeypatch.delenv(name, raising=False)
     gold = np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy"))
     ped = gen.genealogy(gen.genea140)
@@ -1570,6 +1570,19 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
         monkeypatch.setenv("GENPHI_SPARSE_CLASSES", v)
         _assert_equal(gen.phi(ped), gold)
     monkeypatch.delenv("GENPHI_SPARSE_CLASSES", raising=False)
+    # the row-list arenas start small and the calibration run enlarges them where a cut needs more (genea140's cuts 9 and 10 by default;
+    # here from 64 / 5,000 / 300,000 entries on: a leg of the run per enlargement): same cuts, same lists, same matrix
+    k_default, nnz_default = k, nnz
+    for first in ("64", "5000", "300000"):
+        monkeypatch.setenv("GENPHI_SPARSE_ARENA", first)
+        pl = gen.plan(ped)
+        _assert_equal(pl.compute(), gold)
+        assert pl.sparse_levels()[0] == k_default and pl.sparse_levels()[1][:k_default + 1] == nnz_default[:k_default + 1], (first, pl.sparse_levels())
+        _assert_equal(pl.compute(), gold)
+        pl.compute_device(storage64=True)
+        assert np.array_equal(pl.result_to_host_f64(), f64_sparse)
+        pl.close()
+    monkeypatch.delenv("GENPHI_SPARSE_ARENA", raising=False)
     # random mating (every row of every cut new, no dragged members) and overlapping generations, by calibration
     for args, kw in (((30000, 3000, 10), dict(skip_permille=0)), ((30000, 2000, 14), dict(skip_permille=30))):
         ind, fa, mo, sex, pro = synth.random_mating(*args, **kw)
