@@ -818,7 +818,8 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
             if (c < n_cand) {                              // room for the cut behind it in the other arena (lists grow up to ~4 x per cut, less and less)
                 const size_t dense_next = static_cast<size_t>(sl->n_of[c + 1]) * static_cast<size_t>(c + 2 <= sl->S ? sl->n_of[c + 2] : sl->n_of[c + 1]) + 64;
                 const size_t cap_o = std::min(std::min(sl->ent_max, dense_next), 3 * need);
-                if (cap_o > sl->ent_cap[b ^ 1]) {
+                // (small lists only: a cut behind this one that needs more than 256 MB is looked at -- does it pay? -- before anything is allocated for it)
+                if (cap_o > sl->ent_cap[b ^ 1] && cap_o * sizeof(uint2) <= (size_t(256) << 20)) {
                     uint2 *bigger = nullptr;
                     SP_TRY(cached_malloc(reinterpret_cast<void **>(&bigger), cap_o * sizeof(uint2)));
                     const size_t live = static_cast<size_t>(sl->n_ent[c - 1]);       // cut c-1: the source of the leg to come
