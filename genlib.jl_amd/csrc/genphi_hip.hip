@@ -2019,7 +2019,7 @@ struct Tuning {
     int sparse_min_cut = -1;       // GENPHI_SPARSE_MIN_CUT   tuning + test: ... and only when a cut of the sparse run has this many members
     int sparse_chunk = 0;          // GENPHI_SPARSE_CHUNK     tuning: columns per workgroup of the sparse -> dense step
     int sparse_batch = 0;          // GENPHI_SPARSE_BATCH     A/B: list entries in flight per thread of a long row's workgroup, 4 or 8 (default 4; 8 measured slower)
-    int sparse_arena = 0;          // GENPHI_SPARSE_ARENA     test: entries the row-list arenas start with (default 4 Mi; small values exercise their growth)
+    int sparse_arena = 0;          // GENPHI_SPARSE_ARENA     test: entries the row-list arenas start with (default 16 Mi; small values exercise their growth)
     int d2h_chunk_mb = 0;          // GENPHI_D2H_CHUNK_MB     tuning: size of a pinned staging chunk of genphi_result_to_host (default 16, 4 for results below 2 GB)
     int sparse_classes = -1;       // GENPHI_SPARSE_CLASSES   A/B + test: 1 / 0 = a row-list step is always / never one launch per class of row lengths (default: where lengths differ much)
 };

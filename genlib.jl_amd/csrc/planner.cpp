@@ -810,13 +810,15 @@ int build_plan(int64_t n_ind, const int64_t *ind, const int64_t *father, const i
             nn.work.resize(o);
         }
     };
-    // Large plans: eight threads (measured on a GPU box, profiles/microbench/out/r05_planner_threads_*.out: cfg4 44.5 ms with 1 thread,
-    // 28.5 with 4, 25.3 with 8, 23.5 with 16 -- the phases above this one are serial; cfg3s 9.0 -> 7.0).  Small plans stay on the
-    // calling thread: their steps are short and fresh threads cost more than they save (the build container's 8 CPUs even lost time
-    // on cfg4 in round 2: 0.10 -> 0.12 s).  GENPHI_PLAN_THREADS overrides.
+    // Eight threads for plans of 150k members over all cuts and more, four from 50k on (measured on a GPU box,
+    // profiles/microbench/out/r05_planner_threads_*.out: cfg4 44.5 ms with 1 thread, 28.5 with 4, 25.3 with 8, 23.5 with 16 -- the phases
+    // above this one are serial; cfg3s 8.95 -> 7.1 with 8; cfg3 4.13 -> 2.46 with 8; genea140 2.45 -> 1.66 with 4, 1.61 with 8).  Smaller
+    // plans (cfg5: 200 cuts of 50) stay on the calling thread: their steps are shorter than a thread's start.  (The build container's 8
+    // CPUs gain nothing from the threads and lose nothing either.)  GENPHI_PLAN_THREADS overrides.
     int64_t members = 0;
     for (int32_t c = 0; c < L; ++c) members += plan.cut_sizes[c];
-    int n_thr = members >= 400000 ? static_cast<int>(std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2))) : 1;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency() / 2);
+    int n_thr = members >= 150000 ? static_cast<int>(std::min(8u, hw)) : members >= 50000 ? static_cast<int>(std::min(4u, hw)) : 1;
     if (const char *e = env_hook("GENPHI_PLAN_THREADS")) n_thr = std::max(1, std::min(32, std::atoi(e)));
     n_thr = std::min(n_thr, std::max(1, L - 1));
     if (n_thr <= 1) {

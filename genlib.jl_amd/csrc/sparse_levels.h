@@ -47,7 +47,7 @@ struct SparseTuning {
     int chunk_cols = 12288;    // columns per workgroup of the sparse -> dense step (cfg4, same box: 0.62 ms at 8192, 0.56 at 12288, 0.79 at 4096)
     int long_batch = 4;        // list entries a thread of a four-wavefront row keeps in flight (4; 8 = A/B hook: measured SLOWER -- genea140's
                                // largest list steps +12..24 %, cfg3s +22 %, cfg4 the same: r05_ab_sparse_list_step_entries_in_flight_4_vs_8_*.out)
-    int first_entries = 1 << 22;   // entries each row-list arena starts with (32 MB); the calibration run enlarges them where a cut needs more (test hook: small values)
+    int first_entries = 1 << 24;   // entries each row-list arena starts with (128 MB: genea140's and cfg3's lists fit, 11 M and 8.5 M entries); the calibration run enlarges them where a cut needs more (test hook: small values)
     int classes = -1;          // a launch per class of row lengths: -1 = where the rows of a cut differ much in length, 1 / 0 = always / never (A/B hook)
 };
 

@@ -470,6 +470,8 @@ struct SparseLevels {
     size_t ent_cap[2] = {0, 0};      // entries each arena holds: small at first, enlarged by the calibration run where a cut needs it
     size_t ent_max = 0;              // ... up to this many (a cut that needs more is too dense to stay sparse)
     int n_grown = 0;                 // (trace) how often the calibration run enlarged an arena
+    bool lists_fresh = false;        // the calibration run has just written the lists of cut k (its fill launches ARE the list steps of a sweep) and
+                                     // nothing has touched them since: the first sweep starts at the step that turns them into a matrix
     unsigned *stat = nullptr;        // 4 words per cut
     unsigned *stat_host = nullptr;   // pinned copy of them, fetched at the end of a sweep
     std::vector<long long> nnz;      // non-zero entries of Psi_c per cut 0..S (-1 unknown)
@@ -867,8 +869,13 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         size_t need[2] = {1024, 1024};
         for (int c = 0; c <= k; ++c) need[c & 1] = std::max(need[c & 1], static_cast<size_t>(sl->n_ent[c]) + 64);
         SP_TRY(hipStreamSynchronize(stream));
+        // (cut k's lists survive the run only if no later cut was written over them: cut k+2 shares their arena)
+        sl->lists_fresh = true;
+        for (int c = k + 2; c <= n_cand; c += 2)
+            if (st[4 * c + 2] == 0u && st[4 * c + 0] != 0u) sl->lists_fresh = false;
         for (int b = 0; b < 2; ++b) {
             if (need[b] * 2 > sl->ent_cap[b]) continue;    // (not worth a reallocation)
+            if (b == (k & 1)) sl->lists_fresh = false;     // (the lists of cut k go with their arena: the first sweep computes them again)
             (void)cached_free(sl->ent[b]);
             sl->ent[b] = nullptr;
             SP_TRY(cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), need[b] * sizeof(uint2)));
@@ -885,6 +892,7 @@ int sparse_levels_k(const SparseLevels *sl) { return sl ? sl->k : -1; }
 int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std::string &err)
 {
     if (!sl || s < 0 || s >= sl->k) { err = "sparse_levels_enqueue_step: not a sparse step"; return GENPHI_ERR_ARG; }
+    if (sl->lists_fresh) return GENPHI_OK;                 // (first sweep after the calibration run: cut k's lists are there -- genea140 0.3 ms of a one-shot call)
     int rc = s == 0 ? launch_identity(sl, stream, err) : GENPHI_OK;
     if (rc) return rc;
     const std::array<int, 4> &cl = sl->cls[s + 1];
@@ -907,6 +915,7 @@ int sparse_levels_enqueue_step(SparseLevels *sl, int s, hipStream_t stream, std:
 int sparse_levels_enqueue_dense(SparseLevels *sl, void *out, bool f64, bool compact, long long ld, long long width, hipStream_t stream, std::string &err)
 {
     if (!sl || sl->k < 1) { err = "sparse_levels_enqueue_dense: no sparse cut"; return GENPHI_ERR_ARG; }
+    sl->lists_fresh = false;                               // (from the next sweep on the list steps run)
     SpArgs a = args_for(sl, sl->k);
     a.out = out; a.ld = ld; a.width = static_cast<int>(width);
     // columns per workgroup: the member rows in as few equal chunks as the budget allows (the "none" row spans the pitch)

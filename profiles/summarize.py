@@ -61,18 +61,23 @@ except Exception:
 KERNELS = ("level_", "levels_small", "rows_compact", "rows_avg", "drag_rows", "transpose_block", "transpose_slots", "slots_scatter", "slots_clear",
            "copy_block", "pad_zero", "colperm", "group_split", "sparse_step", "sparse_dense", "sparse_identity")
 rows, tot, sweeps, steps = [], 0.0, 0, 0
-# (the first sparse_identity_kernel of a process starts the CALIBRATION run of the plan's sparse cuts, sparse_levels.hip: its list
-# steps are not part of a sweep and are left out)
-n_sparse_ident = 0
+# A plan's sparse cuts (sparse_levels.hip): the first sparse_identity_kernel of the process starts the CALIBRATION run -- its list steps
+# are not part of a sweep and are left out.  The FIRST sweep after it takes cut k's lists as the calibration run left them and starts
+# at sparse_dense_kernel: a partial sweep, listed in the level table but kept out of the per-sweep average.  Every later sweep starts
+# with a sparse_identity_kernel of its own.
+n_sparse_ident, first_sweep = 0, False
 for k in F:
     name = F[k]["name"]
     if not any(t in name for t in KERNELS) or k not in W:
         continue
     if "sparse_identity_kernel" in name:
         n_sparse_ident += 1
+        first_sweep = False
         if n_sparse_ident >= 2:
             sweeps += 1
-    if n_sparse_ident == 1 and "sparse_" in name:
+    if n_sparse_ident == 1 and "sparse_dense_kernel" in name:
+        first_sweep = True
+    if n_sparse_ident == 1 and "sparse_" in name and not first_sweep:
         continue
     m = re.search(r"\(anonymous namespace\)::([A-Za-z_0-9]+(?:<[^>]*>)?)\(", name)      # (the argument list names the namespace again)
     short = (m.group(1) if m else name.split("(")[0]).replace(", ", ",")
@@ -85,7 +90,8 @@ for k in F:
     hit, miss = W[k].get("TCC_HIT_sum", 0.0), W[k].get("TCC_MISS_sum", 0.0)
     rows.append((k, short, round(F[k]["ms"], 4), int(rd), int(wr), round(100 * hit / max(hit + miss, 1), 1),
                  int(T.get(k, {}).get("TCP_TCC_READ_REQ_sum", -1)), int(T.get(k, {}).get("TCP_TCC_WRITE_REQ_sum", -1))))
-    tot += rd + wr
+    if not first_sweep:
+        tot += rd + wr
 with open(os.path.join(dst, f"{tag}_{wl}_levels.csv"), "w") as fh:
     fh.write("dispatch,kernel,ms_under_pmc,hbm_read_bytes,hbm_write_bytes,l2_hit_pct,tcp_tcc_read_req,tcp_tcc_write_req\n")
     for r in rows:

@@ -107,6 +107,58 @@ def make_case(case):
     return r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env
 
 
+def run_case(case, gen, synth, O):
+    """One case end to end: every product path it draws against the oracle, bit for bit.  Returns (failures, env, (n_gen, n_ind, n_pro,
+    skip), in-place steps, sparse cuts)."""
+    n_stay = n_sparse = 0
+    r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env = make_case(case)
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    sort = bool(r.random() < 0.5)                                         # sort=false: the file order is the rank
+    if not sort:
+        ind, fa, mo, sex = synth.parents_first_shuffle(ind, fa, mo, sex, seed=case & 0xffff)
+    env["sort"] = str(sort)
+    ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex}, sort=sort)
+    oped = O.Pedigree(ind, fa, mo, sort=sort)
+    want = oped.phi(pro)
+    n = len(want)
+    what = []
+    try:
+        pl = gen.plan(ped, pro)
+        n_stay += sum(pl.step_slots(k)[0] & 1 for k in range(len(pl.step_modes())))
+        if not np.array_equal(pl.compute(), want):
+            what.append("full")
+        n_sparse += pl.sparse_levels()[0] + 1
+        if pl.sparse_levels()[0] >= 1 and not np.array_equal(pl.compute(no_sparse=True), want):
+            what.append("same-plan-dense")
+        if n > 2:
+            a = int(r.integers(0, n - 1)); b = int(r.integers(a + 1, n + 1))
+            if not np.array_equal(pl.compute(rows=(a, b)), want[a:b]):
+                what.append(f"shard({a},{b})")
+            if not np.array_equal(pl.compute(), want):
+                what.append("full-after-shard")
+        if r.random() < 0.2 and not np.array_equal(pl.compute(kernel=1), want):
+            what.append("naive")
+        pl.close()
+        if r.random() < 0.25:
+            ids = r.choice(ind, size=min(30, len(ind)), replace=False)
+            if not np.array_equal(gen.f(ped, ids), oped.f(ids)):
+                what.append("f")
+        if r.random() < 0.25 and n_ind < 3000:
+            sub = list(dict.fromkeys(int(x) for x in pro))[:40]
+            K = gen.sparse_phi(ped, sub)
+            Ko = O.SparsePhi(oped, sub)
+            got = K.get(np.repeat(sub, len(sub)), np.tile(sub, len(sub))).reshape(len(sub), len(sub)).astype(np.float32)
+            ge, we = K.entries(), Ko.entries()
+            same_entries = sorted(zip(ge[0].tolist(), ge[1].tolist(), ge[2].tolist())) == sorted(zip(we[0].tolist(), we[1].tolist(), we[2].tolist()))
+            if not np.array_equal(got, Ko.matrix()) or repr(K) != Ko.show() or not same_entries or gen.phiMean(K) != Ko.phi_mean():
+                what.append("sparse")
+    except Exception as e:          # noqa: BLE001
+        what.append(f"exception {type(e).__name__}: {e}")
+    return what, env, (n_gen, n_ind, n_pro, skip), n_stay, n_sparse
+
+
 def main():
     import genlib_jl_amd as gen
     from genlib_jl_amd import synth
@@ -118,51 +170,9 @@ def main():
     t0, n_cases, n_fail, n_stay, n_sparse = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         case = int(rng.integers(1 << 30))
-        r, n_gen, n_ind, n_pro, skip, ind, fa, mo, sex, pro, env = make_case(case)
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        sort = bool(r.random() < 0.5)                                         # sort=false: the file order is the rank
-        if not sort:
-            ind, fa, mo, sex = synth.parents_first_shuffle(ind, fa, mo, sex, seed=case & 0xffff)
-        env["sort"] = str(sort)
-        ped = gen.genealogy({"ind": ind, "father": fa, "mother": mo, "sex": sex}, sort=sort)
-        oped = O.Pedigree(ind, fa, mo, sort=sort)
-        want = oped.phi(pro)
-        n = len(want)
-        what = []
-        try:
-            pl = gen.plan(ped, pro)
-            n_stay += sum(pl.step_slots(k)[0] & 1 for k in range(len(pl.step_modes())))
-            if not np.array_equal(pl.compute(), want):
-                what.append("full")
-            n_sparse += pl.sparse_levels()[0] + 1
-            if pl.sparse_levels()[0] >= 1 and not np.array_equal(pl.compute(no_sparse=True), want):
-                what.append("same-plan-dense")
-            if n > 2:
-                a = int(r.integers(0, n - 1)); b = int(r.integers(a + 1, n + 1))
-                if not np.array_equal(pl.compute(rows=(a, b)), want[a:b]):
-                    what.append(f"shard({a},{b})")
-                if not np.array_equal(pl.compute(), want):
-                    what.append("full-after-shard")
-            if r.random() < 0.2 and not np.array_equal(pl.compute(kernel=1), want):
-                what.append("naive")
-            pl.close()
-            if r.random() < 0.25:
-                ids = r.choice(ind, size=min(30, len(ind)), replace=False)
-                if not np.array_equal(gen.f(ped, ids), oped.f(ids)):
-                    what.append("f")
-            if r.random() < 0.25 and n_ind < 3000:
-                sub = list(dict.fromkeys(int(x) for x in pro))[:40]
-                K = gen.sparse_phi(ped, sub)
-                Ko = O.SparsePhi(oped, sub)
-                got = K.get(np.repeat(sub, len(sub)), np.tile(sub, len(sub))).reshape(len(sub), len(sub)).astype(np.float32)
-                ge, we = K.entries(), Ko.entries()
-                same_entries = sorted(zip(ge[0].tolist(), ge[1].tolist(), ge[2].tolist())) == sorted(zip(we[0].tolist(), we[1].tolist(), we[2].tolist()))
-                if not np.array_equal(got, Ko.matrix()) or repr(K) != Ko.show() or not same_entries or gen.phiMean(K) != Ko.phi_mean():
-                    what.append("sparse")
-        except Exception as e:          # noqa: BLE001
-            what.append(f"exception {type(e).__name__}: {e}")
+        what, env, shape, stay, sparse = run_case(case, gen, synth, O)
+        n_gen, n_ind, n_pro, skip = shape
+        n_stay += stay; n_sparse += sparse
         n_cases += 1
         if what:
             n_fail += 1

@@ -1634,6 +1634,27 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
     assert n_by_slot >= 3, n_by_slot
 
 
+def test_stress_cases_that_failed_once(gen, oracle):
+    """Cases of tests/stress_random.py that a build of this repository got wrong, replayed with their knobs (the stress run itself is
+    not part of the suite).  Round 5: the first sweep after the calibration run of the sparse cuts took cut k's lists from the arena
+    although the run had written cut k+2 over them (the Float64 sweep of gen.f and a full sweep, small arenas enlarged cut by cut)."""
+    import sys
+    sys.path.insert(0, HERE)
+    import stress_random
+    from genlib_jl_amd import synth
+    saved = {k: os.environ.get(k) for k in stress_random.KNOBS}
+    try:
+        for case in (266205955, 834111418, 399799883, 314969413):
+            what, env, shape, _, _ = stress_random.run_case(case, gen, synth, oracle)
+            assert not what, (case, shape, env, what)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_plan_memory_estimate_and_kept_blocks(gen):
     """genphi_plan_device_bytes_needed (host only) bounds what a sweep allocates -- slot matrices of in-place runs and a result at the
     run's pitch included (the proband cut of genea140 with a quarter of its individuals as probands stays in place) --, and released
