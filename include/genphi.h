@@ -159,9 +159,10 @@ int genphi_plan_sparse_levels(const genphi_plan *plan, int32_t *k_out, int64_t *
  * arrays): 0 before the first compute and after genphi_plan_release_device.  What a cache of plans budgets with.             */
 int64_t genphi_plan_device_bytes(const genphi_plan *plan);
 
-/* Host only: the device memory a full-result Float32 sweep of this plan will allocate (level matrices -- slot matrices of in-place runs
- * included --, the result at ITS pitch, delivery buffers, index arrays, the row-list arenas of the sparse cuts): what a caller compares
- * with the free memory of a GPU before choosing between replicated levels and column panels.                      */
+/* Host only: an UPPER BOUND of the device memory a full-result Float32 sweep of this plan allocates (level matrices -- slot matrices of
+ * in-place runs included --, the result at ITS pitch, delivery buffers, index arrays, the row-list arenas of the sparse cuts): what a
+ * caller compares with the free memory of a GPU before choosing between replicated levels and column panels.  A sweep
+ * whose leading cuts run on row lists allocates level matrices only for the cuts that exist as matrices (genea140: 0.35 of 3.2 GB).  */
 int64_t genphi_plan_device_bytes_needed(const genphi_plan *plan);
 
 /* 4 * sum_k (n_k^2 + n_{k+1}^2): the algorithmic HBM bytes of one compute. */
