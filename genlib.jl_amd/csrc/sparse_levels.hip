@@ -720,12 +720,24 @@ static double t_dense_from_lists(const SparseLevels *sl, int k)
 }
 static double t_dense_step(const SparseLevels *sl, int s) { return sl->dense_ms[s]; }
 
+// a plan whose sweep stays dense after all keeps its counts (diagnostics) but not the arenas
+static void drop_arenas(SparseLevels *sl, hipStream_t stream)
+{
+    (void)hipStreamSynchronize(stream);
+    for (int b = 0; b < 2; ++b) {
+        if (sl->ent[b]) (void)cached_free(sl->ent[b]);
+        sl->ent[b] = nullptr;
+        sl->bytes -= static_cast<double>(sl->ent_cap[b] * sizeof(uint2));
+        sl->ent_cap[b] = 0;
+    }
+}
+
 int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &err)
 {
     if (!sl) { err = "sparse_levels_calibrate: null handle"; return GENPHI_ERR_ARG; }
     if (sl->calibrated) return GENPHI_OK;
     sl->k = -1;
-    if (sl->tun.force_k == -1) { sl->calibrated = true; return GENPHI_OK; }
+    if (sl->tun.force_k == -1) { sl->calibrated = true; drop_arenas(sl, stream); return GENPHI_OK; }
     const bool trace = std::getenv("GENPHI_TRACE") != nullptr;
     // Every candidate cut in one go, without a word from the host in between: per cut a COUNTING launch (row lengths straight from the
     // bitmaps), a scan that turns lengths into places (sparse_place_kernel), and the launch that writes the lists where they belong --
@@ -811,10 +823,14 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
                 if (trace) std::fprintf(stderr, "[genphi trace]   sparse cut %2d needs %zu list entries: %s\n", c, need, pays ? "arena enlarged" : "not worth its lists, the run ends");
                 if (!pays) break;
             }
-            (void)cached_free(sl->ent[b]);                 // (holds cut c-2: dead)
-            sl->ent[b] = nullptr;
             const size_t cap_b = std::min(sl->ent_max, need + need / 8 + 64);
-            SP_TRY(cached_malloc(reinterpret_cast<void **>(&sl->ent[b]), cap_b * sizeof(uint2)));
+            uint2 *larger = nullptr;
+            if (cached_malloc(reinterpret_cast<void **>(&larger), cap_b * sizeof(uint2)) != hipSuccess) {
+                (void)hipGetLastError();                   // (no memory for this cut's lists: the run ends at the cut before it, the sweep goes on densely from there)
+                break;
+            }
+            (void)cached_free(sl->ent[b]);                 // (holds cut c-2: dead)
+            sl->ent[b] = larger;
             sl->bytes += static_cast<double>(cap_b * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b] * sizeof(uint2));
             sl->ent_cap[b] = cap_b;
             if (c < n_cand) {                              // room for the cut behind it in the other arena (lists grow up to ~4 x per cut, less and less)
@@ -823,14 +839,16 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
                 // (small lists only: a cut behind this one that needs more than 256 MB is looked at -- does it pay? -- before anything is allocated for it)
                 if (cap_o > sl->ent_cap[b ^ 1] && cap_o * sizeof(uint2) <= (size_t(256) << 20)) {
                     uint2 *bigger = nullptr;
-                    SP_TRY(cached_malloc(reinterpret_cast<void **>(&bigger), cap_o * sizeof(uint2)));
+                    if (cached_malloc(reinterpret_cast<void **>(&bigger), cap_o * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); bigger = nullptr; }
                     const size_t live = static_cast<size_t>(sl->n_ent[c - 1]);       // cut c-1: the source of the leg to come
-                    SP_TRY(hipMemcpyAsync(bigger, sl->ent[b ^ 1], live * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
-                    SP_TRY(hipStreamSynchronize(stream));
-                    (void)cached_free(sl->ent[b ^ 1]);
-                    sl->ent[b ^ 1] = bigger;
-                    sl->bytes += static_cast<double>(cap_o * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b ^ 1] * sizeof(uint2));
-                    sl->ent_cap[b ^ 1] = cap_o;
+                    if (bigger) {                            // (room for the next cut is a convenience: without it that cut asks for itself)
+                        SP_TRY(hipMemcpyAsync(bigger, sl->ent[b ^ 1], live * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+                        SP_TRY(hipStreamSynchronize(stream));
+                        (void)cached_free(sl->ent[b ^ 1]);
+                        sl->ent[b ^ 1] = bigger;
+                        sl->bytes += static_cast<double>(cap_o * sizeof(uint2)) - static_cast<double>(sl->ent_cap[b ^ 1] * sizeof(uint2));
+                        sl->ent_cap[b ^ 1] = cap_o;
+                    }
                 }
             }
             ++sl->n_grown;
@@ -845,7 +863,7 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         SP_TRY(hipMemcpyAsync(sl->order[c], orders[c].data(), orders[c].size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SP_TRY(hipStreamSynchronize(stream));                  // (`orders` goes out of scope)
     sl->calibrated = true;                                 // (from here on rows go where this run put them)
-    if (last < 1) return GENPHI_OK;
+    if (last < 1) { drop_arenas(sl, stream); return GENPHI_OK; }
     int k = last;
     if (sl->tun.force_k < 0) {
         // the last sparse cut: the cheapest of "lists up to cut k, the dense matrix of cut k+1 from them, dense beyond"
@@ -859,10 +877,10 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
             for (int s = kk + 1; s <= last; ++s) t += t_dense_step(sl, s);
             if (t < best) { best = t; k = kk; }
         }
-        if (k < 1) return GENPHI_OK;
+        if (k < 1) { drop_arenas(sl, stream); return GENPHI_OK; }
         int widest = 0;
         for (int c = 0; c <= k + 1; ++c) widest = std::max(widest, sl->n_of[c]);
-        if (widest < sl->tun.min_cut) return GENPHI_OK;
+        if (widest < sl->tun.min_cut) { drop_arenas(sl, stream); return GENPHI_OK; }
     }
     sl->k = k;
     {   // the arenas of the calibration run were sized for cuts of unknown density: now each holds exactly the largest cut it is used for
