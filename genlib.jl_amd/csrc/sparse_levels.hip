@@ -60,6 +60,8 @@ struct SpArgs {
     const unsigned *stop;         // (calibration run) != nullptr: a word that names the first cut NOT to compute once a cut proved too dense (0: none
     unsigned level;               //   yet) -- launches for that cut and the ones behind it end at once; level = the cut this launch writes
     unsigned ent_cap;             // entries the arena written holds
+    unsigned nz_lo, nz_hi;        // (calibration run, writing launches) nz_hi != 0: this launch writes the rows with nz_lo < non-zero entries <= nz_hi
+                                  //   (nz_lo = 0: from empty rows on) -- the counting launch has left every row's count in rnz_out
     const int *chn_off;           // children of member q of cut s+1 in cut s+2: chn[chn_off[q] .. chn_off[q + 1])
     const unsigned *chn;          //   position in cut s+2 | 0x80000000 when the child is q itself (dragged: weight 1)
     const int *mt_off;            // mates of member p of cut s+1: mt[mt_off[p] .. mt_off[p + 1]) = (B, i) for every new member i of
@@ -207,6 +209,10 @@ __global__ void __launch_bounds__(NT) sparse_step_kernel(const SpArgs a)
     }
     const int w = a.remap ? xcd_remap(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x);
     const int i = a.rows ? a.rows[w] : w;
+    if (a.nz_hi != 0u) {                                   // (workgroup-uniform) a row of another launch's class of lengths
+        const unsigned nz = a.rnz_out[i];
+        if (nz > a.nz_hi || (a.nz_lo != 0u && nz <= a.nz_lo)) return;
+    }
     const int A = a.srcA[i], B = a.srcB[i];
     const bool new_i = a.ord[i] < 0;
     const int none = a.n_prev;
@@ -687,11 +693,12 @@ static int launch_identity(SparseLevels *sl, hipStream_t stream, std::string &er
 // one launch of the row-list step: n_rows members (rows == nullptr: all of them, in order), `cap` entries per row in LDS, four
 // wavefronts per row when `wide`
 static int launch_rows(SparseLevels *sl, int s, const int *rows, int n_rows, int cap, bool wide, hipStream_t stream, std::string &err,
-                       bool count_only = false, bool calibrating = false)
+                       bool count_only = false, bool calibrating = false, unsigned nz_lo = 0u, unsigned nz_hi = 0u)
 {
     if (n_rows <= 0) return GENPHI_OK;
     SpArgs a = args_for(sl, s);
     a.count_only = count_only ? 1 : 0;
+    a.nz_lo = nz_lo; a.nz_hi = nz_hi;
     a.stop = calibrating ? sl->stat + 3 : nullptr;         // (word 3 of cut 0's counters, cleared by sparse_identity_kernel)
     a.level = static_cast<unsigned>(s + 1);
     a.rows = rows;
@@ -744,14 +751,17 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
     // the form every later sweep runs.  (The first version placed rows with an atomic cursor and synchronised after every cut: one
     // same-address device-scope atomic per row is ~26 ns -- 1.9 of the 2.3 ms it took on genea140.)  A cut that turns out too dense
     // voids itself (its rows do not fit the LDS of the writing launch, or its lists the arena): everything behind it sees empty lists.
+    PhaseTrace tr;                                         // (GENPHI_TRACE: where the calibration run's time goes)
     int rc = launch_identity(sl, stream, err);
     if (rc) return rc;
     const int n_cand = sl->tun.force_k >= 0 ? std::min(sl->S - 1, sl->tun.force_k) : sl->S - 1;   // cuts 1..n_cand may be kept as lists
     std::vector<unsigned> st(4 * (static_cast<size_t>(sl->S) + 1), 0u), rnz_all;
+    // (host images laid out like the device blobs -- cut c at the offset of sl->rnz[c] / sl->order[c] -- so that a leg's row counts
+    // come back in ONE copy and the row orders go out in one: ten small pageable copies were 0.15 ms of genea140's run)
     std::vector<size_t> rnz_at(sl->S + 1, 0);
-    size_t rnz_total = 0;
-    for (int c = 1; c <= n_cand; ++c) { rnz_at[c] = rnz_total; rnz_total += static_cast<size_t>(sl->n_of[c]); }
-    rnz_all.resize(std::max<size_t>(rnz_total, 1));
+    for (int c = 0; c < sl->S; ++c) rnz_at[c] = static_cast<size_t>(sl->rnz[c] - sl->rnz_blob);
+    const size_t blob_words = sl->S > 0 ? rnz_at[sl->S - 1] + static_cast<size_t>(sl->n_of[sl->S - 1]) : 1;
+    rnz_all.resize(std::max<size_t>(blob_words, 1));
     int last = 0;                                          // last cut whose lists are valid and sparse enough
     std::vector<int> order, cnt;
     std::vector<std::vector<int>> orders(sl->S + 1);
@@ -769,14 +779,24 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
                                static_cast<unsigned>(std::min<size_t>(sl->ent_cap[(s + 1) & 1], 0xffffffffu)), stop_entries, sl->stat + 4 * (s + 1), sl->stat + 3,
                                static_cast<unsigned>(s + 1));
             SP_TRY(hipGetLastError());
-            rc = launch_rows(sl, s, nullptr, n, sl->cap_cal, wide, stream, err, /*count_only=*/false, /*calibrating=*/true);
+            // the writing launches by class of row lengths, as in a sweep (the counting launch has left every row's count on the device;
+            // the host does not know them yet, so every launch is offered every row and a row picks its launch): short rows on one
+            // wavefront with a small row buffer -- one launch with room for the longest row a cut may have ran at a third of a sweep's
+            // occupancy (genea140: the run 1.2 -> ... ms of a one-shot call)
+            const int cap = sl->cap_cal;
+            rc = launch_rows(sl, s, nullptr, n, std::min(cap, 256), false, stream, err, false, true, 0u, 256u);
+            if (rc == GENPHI_OK && cap > 256) rc = launch_rows(sl, s, nullptr, n, std::min(cap, 1024), true, stream, err, false, true, 256u, 1024u);
+            if (rc == GENPHI_OK && cap > 1024) rc = launch_rows(sl, s, nullptr, n, cap, true, stream, err, false, true, 1024u, 0xffffffffu);
             if (rc) return rc;
         }
         // one round trip per leg: the counters of every cut and every row's number of non-zero entries
         SP_TRY(hipMemcpyAsync(st.data(), sl->stat, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        for (int c = from; c <= n_cand; ++c)
-            SP_TRY(hipMemcpyAsync(rnz_all.data() + rnz_at[c], sl->rnz[c], static_cast<size_t>(sl->n_of[c]) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        if (from <= n_cand)
+            SP_TRY(hipMemcpyAsync(rnz_all.data() + rnz_at[from], sl->rnz[from],
+                                  (rnz_at[n_cand] + static_cast<size_t>(sl->n_of[n_cand]) - rnz_at[from]) * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        tr.mark("    calibration: a leg enqueued");
         SP_TRY(hipStreamSynchronize(stream));
+        tr.mark("    calibration: a leg done on the GPU");
         int grow_at = 0;
         for (int s = from - 1; s < n_cand; ++s) {
             const int n = sl->n_of[s + 1];
@@ -859,9 +879,14 @@ int sparse_levels_calibrate(SparseLevels *sl, hipStream_t stream, std::string &e
         }
     }
     if (trace && sl->n_grown) std::fprintf(stderr, "[genphi trace]   sparse: arenas enlarged %d times (%zu + %zu entries)\n", sl->n_grown, sl->ent_cap[0], sl->ent_cap[1]);
-    for (int c = 1; c <= last; ++c)
-        SP_TRY(hipMemcpyAsync(sl->order[c], orders[c].data(), orders[c].size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    SP_TRY(hipStreamSynchronize(stream));                  // (`orders` goes out of scope)
+    tr.mark("    calibration: rows sorted by length (host)");
+    if (last >= 1) {
+        std::vector<int> ord_all(rnz_at[last] + static_cast<size_t>(sl->n_of[last]) - rnz_at[1], 0);
+        for (int c = 1; c <= last; ++c) std::copy(orders[c].begin(), orders[c].end(), ord_all.begin() + static_cast<std::ptrdiff_t>(rnz_at[c] - rnz_at[1]));
+        SP_TRY(hipMemcpyAsync(sl->order[1], ord_all.data(), ord_all.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        SP_TRY(hipStreamSynchronize(stream));              // (`ord_all` goes out of scope)
+    }
+    tr.mark("    calibration: row orders to the device");
     sl->calibrated = true;                                 // (from here on rows go where this run put them)
     if (last < 1) { drop_arenas(sl, stream); return GENPHI_OK; }
     int k = last;
