@@ -1634,6 +1634,35 @@ def test_sparse_leading_levels(gen, oracle, monkeypatch):
     assert n_by_slot >= 3, n_by_slot
 
 
+def test_kept_blocks_respect_their_budget():
+    """csrc/devcache.hip in a process of its own (GENPHI_KEEP_MB is read once): with a 64 MB budget the blocks of a released 350 MB plan
+    are kept only up to the budget, the oldest making room for the newest, and the next plans compute the same matrix from recycled blocks;
+    with a budget of 0 nothing is kept."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import genlib_jl_amd as gen\n"
+        "from genlib_jl_amd import _capi\n"
+        "gold = np.load(%r)\n"
+        "ped = gen.genealogy(gen.genea140)\n"
+        "budget = int(os.environ['GENPHI_KEEP_MB']) << 20\n"
+        "for rep in range(3):\n"
+        "    pl = gen.plan(ped); phi = pl.compute(); pl.close()\n"
+        "    assert np.array_equal(phi, gold), rep\n"
+        "    kept = _capi.cached_bytes()\n"
+        "    assert kept <= budget, (rep, kept, budget)\n"
+        "    assert (kept > 0) == (budget > 0), (rep, kept, budget)\n"
+        "_capi.release_cached(); assert _capi.cached_bytes() == 0\n"
+        "print('ok', budget)\n"
+    ) % (os.path.dirname(HERE), os.path.join(HERE, "golden", "genea140_phi_oracle.npy"))
+    for mb in ("64", "0"):
+        env = dict(os.environ, GENPHI_KEEP_MB=mb, GENPHI_PLAN_CACHE="0")
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert run.returncode == 0 and "ok" in run.stdout, (mb, run.stdout[-500:], run.stderr[-2000:])
+
+
 def test_stress_cases_that_failed_once(gen, oracle):
     """Cases of tests/stress_random.py that a build of this repository got wrong, replayed with their knobs (the stress run itself is
     not part of the suite).  Round 5: the first sweep after the calibration run of the sparse cuts took cut k's lists from the arena
