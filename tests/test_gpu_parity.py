@@ -1699,7 +1699,7 @@ def test_plan_memory_estimate_and_kept_blocks(gen):
         have = pl.device_bytes
         assert 0 < have <= need <= 1.5 * have + (3 << 30), (have, need)
         pl.close()
-    assert _capi.cached_bytes() > 0
+    assert _capi.cached_bytes() > 0 or os.environ.get("GENPHI_KEEP_MB") == "0"      # (the suite is also run with nothing kept)
     _capi.release_cached()
     assert _capi.cached_bytes() == 0
     _assert_equal(gen.phi(ped), np.load(os.path.join(HERE, "golden", "genea140_phi_oracle.npy")))
