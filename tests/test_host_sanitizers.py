@@ -29,6 +29,9 @@ def test_planner_and_loader_under_sanitizers(san, tmp_path):
     env.pop("GENPHI_ENV_HOOKS", None)                               # (the planner's default thread counts)
     run = subprocess.run([exe, os.path.join(DATA, "genea140.csv"), os.path.join(DATA, "geneaJi.csv")], capture_output=True, text=True, env=env,
                          timeout=600)
+    if run.returncode != 0 and not run.stdout and any(t in run.stderr for t in ("unexpected memory mapping", "runtime does not come first", "failed to intercept",
+                                                                                     "ReserveShadowMemoryRange failed")):
+        pytest.skip("the sanitizer runtime does not start in this environment: " + run.stderr[:200])
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
     assert "host sanitizer run: ok" in run.stdout
     assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr[-3000:]
